@@ -1,0 +1,236 @@
+/*
+ * pandora_amd C ABI: the MI355X drop-in boundary for the read -> PRG minimizer
+ * path of `pandora map` (leoisl/pandora).
+ *
+ * The reference has no FFI layer: the path sits behind plain C++ functions
+ * (include/utils.h:66-90).  A maintainer replaces the body of
+ * pangraph_from_read_file (src/utils.cpp:379-455) with calls to this library;
+ * every entry point below names the reference code it stands in for.
+ *
+ * Conventions: every function returns 0 on success and a non-zero PMAP_E* code
+ * on failure; pmap_last_error() then returns a message (thread local).  All
+ * pointers in the signatures are HOST pointers unless the name says `dev`.
+ * Calls are blocking.  One process drives one GPU (select it with pmap_init).
+ */
+#ifndef PANDORA_AMD_H
+#define PANDORA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMAP_OK 0
+#define PMAP_EINVAL 1   /* bad argument / malformed input (reference: assert or exit(1)) */
+#define PMAP_EHIP 2     /* a HIP runtime call failed */
+#define PMAP_EIO 3      /* file could not be opened or parsed (reference: exit(1)) */
+#define PMAP_ELIMIT 4   /* a documented size limit was exceeded */
+#define PMAP_EDUP 5     /* duplicate (key, prg, path, strand) record: the reference would abort in MinimizerHits::sort (src/minihits.cpp:44-46) */
+
+typedef struct pmap_index pmap_index_t;       /* Index::minhash flattened and resident in HBM */
+typedef struct pmap_reads pmap_reads_t;       /* a batch of reads, 2-bit packed, resident in HBM */
+typedef struct pmap_result pmap_result_t;     /* minimizers / hits / clusters of one batch, in HBM */
+typedef struct pmap_pangraph pmap_pangraph_t; /* host-side pangenome::Graph summary */
+
+const char *pmap_last_error(void);
+
+/* Selects the GPU this process drives and creates the library's stream.
+ * device < 0 keeps the current device. */
+int pmap_init(int device);
+
+/* ---------------------------------------------------------------- index */
+
+/* Flat view of Index::minhash (include/index.h:16) as the caller holds it:
+ * key i owns records [rec_off[i], rec_off[i+1]); record j is a MiniRecord
+ * (include/minirecord.h:9-14) whose prg::Path is the intervals
+ * [path_off[j], path_off[j+1]) given as (start, length).  min_path_length[p] is
+ * prgs[p]->kmer_prg.min_path_length() (src/kmergraph.cpp:664-684). */
+typedef struct {
+    uint32_t k;
+    uint64_t n_keys;
+    const uint64_t *keys;
+    const uint64_t *rec_off;
+    uint64_t n_recs;
+    const uint32_t *rec_prg;
+    const uint32_t *rec_knode;
+    const uint8_t *rec_strand;
+    const uint64_t *path_off;
+    const uint32_t *iv_start;
+    const uint32_t *iv_len;
+    uint32_t n_prg;
+    const uint32_t *min_path_length;
+} pmap_index_desc_t;
+
+/* Replaces the unordered_map behind Index::minhash / Index::add_record
+ * (src/index.cpp:20-37): builds the open-addressing table + CSR record array +
+ * per-(prg,path) ranks (order of prg::Path::operator<, src/prg/path.cpp:166-183)
+ * and uploads them.  Record indices reported by results are indices into the
+ * caller's arrays. */
+int pmap_index_create(const pmap_index_desc_t *desc, pmap_index_t **out);
+
+/* Replaces Index::load (src/index.cpp:75-124): parses the reference's text
+ * `.idx` format.  min_path_length as above (n_prg entries). */
+int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg, const uint32_t *min_path_length,
+                    pmap_index_t **out);
+
+/* Replaces KmerGraph::load + KmerGraph::min_path_length
+ * (src/kmergraph.cpp:716-820, 664-684) for one kmer-graph GFA file. */
+int pmap_gfa_min_path_length(const char *gfa_path, uint32_t *out);
+
+typedef struct {
+    uint32_t k;
+    uint64_t n_keys, n_recs, n_paths, table_slots, device_bytes;
+    uint32_t n_prg;
+} pmap_index_info_t;
+int pmap_index_info(const pmap_index_t *idx, pmap_index_info_t *info);
+
+/* Host copy of the flattened records, in the caller's record numbering
+ * (what Index::save would write, src/index.cpp:51-68).  Any pointer may be
+ * NULL.  path_rank[j] orders records of one prg as prg::Path::operator<. */
+int pmap_index_records(const pmap_index_t *idx, uint64_t *key_of_rec, uint32_t *rec_prg, uint32_t *rec_knode,
+                       uint8_t *rec_strand, uint32_t *path_rank, uint64_t *path_off);
+int pmap_index_intervals(const pmap_index_t *idx, uint32_t *iv_start, uint32_t *iv_len, uint64_t *n_intervals);
+void pmap_index_destroy(pmap_index_t *idx);
+
+/* ---------------------------------------------------------------- reads */
+
+/* Uploads a batch of reads (what FastaqHandler::get_next yields,
+ * src/fastaq_handler.cpp:43-71): read i is bases[offsets[i] .. offsets[i+1]) and
+ * gets read id first_read_id + i.  On the device the batch is encoded with the
+ * nt4 table (src/inthash.cpp:42-63) into 2 bits per base plus one "has a
+ * non-ACGT letter" flag per read (src/seq.cpp:49-53). */
+int pmap_reads_create(const char *bases, const uint64_t *offsets, uint32_t n_reads, uint32_t first_read_id,
+                      pmap_reads_t **out);
+/* Re-runs only the device encode kernel of an uploaded batch (for measurement). */
+int pmap_reads_repack(pmap_reads_t *reads);
+int pmap_reads_info(const pmap_reads_t *reads, uint32_t *n_reads, uint64_t *n_bases, uint64_t *device_bytes);
+void pmap_reads_destroy(pmap_reads_t *reads);
+
+/* ---------------------------------------------------------------- map */
+
+#define PMAP_STAGE_SKETCH 1   /* Seq::minimizer_sketch              src/seq.cpp:91-122 */
+#define PMAP_STAGE_HITS 2     /* add_read_hits                      src/utils.cpp:167-187 */
+#define PMAP_STAGE_SORT 3     /* MinimizerHits::sort                src/minihits.cpp:42-53 */
+#define PMAP_STAGE_CLUSTER 4  /* define_clusters                    src/utils.cpp:189-249 */
+
+typedef struct {
+    uint32_t w, k;
+    int32_t max_diff;           /* src/utils.cpp:209 */
+    float fraction;             /* fraction_kmers_required_for_cluster, src/utils.cpp:394 */
+    uint32_t min_cluster_size;
+    uint32_t expected_kmers;    /* expected_number_kmers_in_short_read_sketch, src/utils.cpp:395,413-416 */
+    uint32_t last_stage;        /* PMAP_STAGE_*; 0 = all */
+    uint32_t profile;           /* 1: record per-stage HIP-event times; 2: also per kernel */
+} pmap_params_t;
+
+/* 0.5 / exp(e_rate * k) as src/utils.cpp:394 evaluates it (float). */
+float pmap_fraction(float e_rate, uint32_t k);
+
+/* Replaces, for one batch of reads, the chain
+ *   Seq::minimizer_sketch -> add_read_hits -> MinimizerHits::sort -> define_clusters
+ * (src/seq.cpp:91-122, src/utils.cpp:167-249, src/minihits.cpp:42-53), entirely
+ * on the GPU.  *result may point to a result of an earlier call, whose device
+ * buffers are then reused (they only grow); pass a pointer to NULL the first
+ * time. */
+int pmap_map(const pmap_index_t *idx, const pmap_reads_t *reads, const pmap_params_t *prm,
+             pmap_result_t **result);
+
+#define PMAP_N_TIMERS 8
+typedef struct {
+    uint32_t n_reads;
+    uint64_t n_bases;
+    uint64_t n_minimizers;
+    uint64_t n_hits;
+    uint64_t n_clusters_all;    /* before the size threshold */
+    uint64_t n_clusters;        /* kept by define_clusters */
+    /* HIP-event times of the last pmap_map with profile=1, milliseconds:
+     * 0 sketch, 1 probe (count+scan+scatter), 2 sort, 3 cluster, 4 total */
+    float ms[PMAP_N_TIMERS];
+} pmap_counts_t;
+int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out);
+
+/* Per-kernel HIP-event times (milliseconds, on the library's stream) of the
+ * last pmap_map call made with profile=2.  ms has PMAP_N_KERNELS entries;
+ * pmap_kernel_name(i) names entry i. */
+#define PMAP_N_KERNELS 16
+int pmap_result_kernel_ms(const pmap_result_t *res, float *ms);
+const char *pmap_kernel_name(int i);
+
+/* Seq::sketch of every read, concatenated in (read, position) order. */
+int pmap_result_minimizers(const pmap_result_t *res, uint64_t *kmer, uint32_t *read_id, uint32_t *pos,
+                           uint8_t *strand);
+/* MinimizerHits::hits in MinimizerHit::operator< order (src/minihit.cpp:44-66).
+ * sorted=0 returns them in emission order (after add_read_hits, before sort). */
+int pmap_result_hits(const pmap_result_t *res, int sorted, uint32_t *read_id, uint32_t *pos, uint32_t *prg_id,
+                     uint32_t *rec, uint8_t *is_forward);
+/* Clusters kept by define_clusters, ordered by their first hit; cluster c is
+ * sorted hits [begin[c], begin[c]+size[c]). */
+int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, uint32_t *size, uint32_t *read_id,
+                         uint32_t *prg_id, uint8_t *is_forward, uint32_t *first_pos, uint32_t *last_pos,
+                         uint32_t *first_rank);
+void pmap_result_destroy(pmap_result_t *res);
+
+/* ---------------------------------------------------------------- host stages */
+
+/* clusterComp order (src/minihits.cpp:95-109) followed by filter_clusters
+ * (src/utils.cpp:251-288) over cluster summaries.  order[j] = input index of
+ * the j-th cluster in clusterComp order; alive[j] = 1 if that cluster survives. */
+int pmap_filter_clusters(uint64_t n, const uint32_t *read_id, const uint32_t *first_pos, const uint32_t *size,
+                         const uint32_t *prg_id, const uint32_t *first_rank, const uint8_t *is_forward,
+                         const uint32_t *last_pos, uint64_t *order, uint8_t *alive);
+
+/* FastaqHandler (src/fastaq_handler.cpp:12-71) over a plain or gzip file:
+ * yields the reads of `while (!fh.eof()) fh.get_next()`.  bases/offsets/names
+ * are malloc'd; free with pmap_free. */
+int pmap_read_fastaq(const char *path, char **bases, uint64_t **offsets, uint32_t *n_reads, char **names,
+                     uint64_t **name_offsets);
+void pmap_free(void *p);
+
+typedef struct {
+    uint32_t w, k;
+    int32_t max_diff;
+    float e_rate;
+    uint32_t min_cluster_size;  /* default 10 */
+    uint32_t genome_size;       /* default 5000000 */
+    int illumina;
+    int clean;                  /* must be 0: the de Bruijn cleaning step (src/noise_filtering.cpp) is not part of this library */
+    uint32_t max_covg;          /* default 300 */
+    uint32_t batch_bases;       /* reads per device batch are cut at this many bases; 0 = default */
+} pmap_map_args_t;
+
+/* Replaces pangraph_from_read_file (src/utils.cpp:379-455) with clean=false:
+ * reads the file, applies the coverage / 10M-read stops, maps every batch on
+ * the GPU, runs filter_clusters and performs the add_node sequence
+ * (src/pangenome/pangraph.cpp:126-140) into a host summary.  *covg is the
+ * function's return value. */
+int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx, const pmap_map_args_t *args,
+                                 pmap_pangraph_t **out, uint32_t *covg);
+
+typedef struct {
+    uint32_t n_nodes, n_reads;
+    uint64_t n_read_nodes;      /* sum over reads of len(Read::nodes) */
+    uint64_t n_hits;            /* sum over reads and prgs of len(Read::hits[prg]) */
+    uint64_t n_add_node_calls;
+} pmap_pangraph_info_t;
+int pmap_pangraph_info(const pmap_pangraph_t *pg, pmap_pangraph_info_t *info);
+/* Nodes sorted by node id: prg_id and covg (pangenome::Node, number of add_node calls). */
+int pmap_pangraph_nodes(const pmap_pangraph_t *pg, uint32_t *prg_id, uint32_t *covg);
+/* Reads sorted by id; read i owns entries [node_off[i], node_off[i+1]) of
+ * node_prg / node_orientation (pangenome::Read::nodes / node_orientations). */
+int pmap_pangraph_reads(const pmap_pangraph_t *pg, uint32_t *read_id, uint64_t *node_off, uint32_t *node_prg,
+                        uint8_t *node_orientation);
+/* Read::hits flattened: sorted by (read id, prg id, pComp_path order
+ * src/minihits.cpp:77-93). */
+int pmap_pangraph_hits(const pmap_pangraph_t *pg, uint32_t *read_id, uint32_t *prg_id, uint32_t *pos,
+                       uint32_t *rec, uint8_t *is_forward);
+/* The add_node call sequence: (prg_id, read_id, cluster size, is_forward of first hit). */
+int pmap_pangraph_calls(const pmap_pangraph_t *pg, uint32_t *prg_id, uint32_t *read_id, uint32_t *size,
+                        uint8_t *is_forward);
+void pmap_pangraph_destroy(pmap_pangraph_t *pg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

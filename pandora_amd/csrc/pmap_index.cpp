@@ -1,0 +1,402 @@
+// Host side of the flat minimizer index: replaces Index::minhash
+// (include/index.h:16), Index::add_record / Index::load (src/index.cpp:20-37,
+// 75-124) and the per-PRG KmerGraph::min_path_length value
+// (src/kmergraph.cpp:664-684, 716-820).
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+
+#include "pmap_internal.h"
+
+static thread_local std::string g_error;
+
+void pmap_set_error(const std::string &msg) { g_error = msg; }
+
+int pmap_fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+extern "C" const char *pmap_last_error(void) { return g_error.c_str(); }
+
+// prg::Path::operator< (src/prg/path.cpp:166-183) with Interval::operator<
+// (src/interval.cpp:47-53) as a three-way comparison over flat intervals.
+static int path_cmp(const uint32_t *as, const uint32_t *al, uint64_t an, const uint32_t *bs, const uint32_t *bl,
+                    uint64_t bn) {
+    uint64_t n = an < bn ? an : bn;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (as[i] != bs[i]) return as[i] < bs[i] ? -1 : 1;
+        if (al[i] != bl[i]) return al[i] < bl[i] ? -1 : 1;
+    }
+    if (an != bn) return an < bn ? -1 : 1;   // a strict prefix is the smaller path
+    return 0;
+}
+
+int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
+    if (d->k < 1 || d->k > 31)
+        return pmap_fail(PMAP_EINVAL, "k must be in [1,31]: the 2k-bit hash mask overflows at k=32 (src/seq.cpp:97)");
+    if (d->n_recs >= 0xFFFFFFFFull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-2 index records");
+    if (d->n_prg >= 0x7FFFFFFFu) return pmap_fail(PMAP_ELIMIT, "more than 2^31-2 PRGs");
+    if (d->n_keys && d->rec_off[d->n_keys] != d->n_recs)
+        return pmap_fail(PMAP_EINVAL, "rec_off[n_keys] != n_recs");
+    const uint64_t n_iv = d->n_recs ? d->path_off[d->n_recs] : 0;
+    const uint64_t key_limit = 1ULL << (2 * d->k);
+
+    idx->k = d->k;
+    idx->n_prg = d->n_prg;
+    idx->n_recs = d->n_recs;
+    idx->rec_prg.assign(d->rec_prg, d->rec_prg + d->n_recs);
+    idx->rec_knode.assign(d->rec_knode, d->rec_knode + d->n_recs);
+    idx->rec_strand.assign(d->rec_strand, d->rec_strand + d->n_recs);
+    idx->path_off.assign(d->path_off, d->path_off + d->n_recs + (d->n_recs ? 1 : 0));
+    if (idx->path_off.empty()) idx->path_off.push_back(0);
+    idx->iv_start.assign(d->iv_start, d->iv_start + n_iv);
+    idx->iv_len.assign(d->iv_len, d->iv_len + n_iv);
+    idx->min_path_length.assign(d->min_path_length, d->min_path_length + d->n_prg);
+    idx->key_of_rec.assign(d->n_recs, 0);
+    idx->path_rank.assign(d->n_recs, 0);
+
+    for (uint64_t i = 0; i < d->n_keys; ++i) {
+        if (d->keys[i] >= key_limit) return pmap_fail(PMAP_EINVAL, "index key does not fit in 2k bits");
+        if (d->rec_off[i] > d->rec_off[i + 1]) return pmap_fail(PMAP_EINVAL, "rec_off not monotone");
+        for (uint64_t j = d->rec_off[i]; j < d->rec_off[i + 1]; ++j) idx->key_of_rec[j] = d->keys[i];
+    }
+    for (uint64_t j = 0; j < d->n_recs; ++j) {
+        if (d->rec_prg[j] >= d->n_prg) return pmap_fail(PMAP_EINVAL, "record prg_id >= n_prg");
+        if (d->rec_knode[j] >= 0x7FFFFFFFu) return pmap_fail(PMAP_ELIMIT, "kmer node id >= 2^31-1");
+        if (d->path_off[j] > d->path_off[j + 1]) return pmap_fail(PMAP_EINVAL, "path_off not monotone");
+        uint64_t len = 0;
+        for (uint64_t q = d->path_off[j]; q < d->path_off[j + 1]; ++q) len += d->iv_len[q];
+        if (len != d->k)   // the reference asserts this when the record is hit (src/minihit.cpp:17)
+            return pmap_fail(PMAP_EINVAL, "a record's path length differs from k");
+    }
+
+    // rank of every (prg, path): order of (prg_id, prg::Path::operator<)
+    std::vector<uint32_t> by_path(d->n_recs);
+    std::iota(by_path.begin(), by_path.end(), 0u);
+    auto pcmp = [&](uint32_t a, uint32_t b) {
+        if (d->rec_prg[a] != d->rec_prg[b]) return d->rec_prg[a] < d->rec_prg[b] ? -1 : 1;
+        uint64_t a0 = d->path_off[a], a1 = d->path_off[a + 1], b0 = d->path_off[b], b1 = d->path_off[b + 1];
+        return path_cmp(d->iv_start + a0, d->iv_len + a0, a1 - a0, d->iv_start + b0, d->iv_len + b0, b1 - b0);
+    };
+    std::sort(by_path.begin(), by_path.end(), [&](uint32_t a, uint32_t b) { return pcmp(a, b) < 0; });
+    uint32_t rank = 0;
+    for (uint64_t i = 0; i < d->n_recs; ++i) {
+        if (i > 0 && pcmp(by_path[i - 1], by_path[i]) != 0) ++rank;
+        idx->path_rank[by_path[i]] = rank;
+    }
+    idx->n_paths = d->n_recs ? rank + 1 : 0;
+
+    // group equal keys (Index::load appends the records of a repeated key line, src/index.cpp:97-110)
+    std::vector<uint64_t> korder(d->n_keys);
+    std::iota(korder.begin(), korder.end(), 0ull);
+    std::sort(korder.begin(), korder.end(), [&](uint64_t a, uint64_t b) {
+        return d->keys[a] != d->keys[b] ? d->keys[a] < d->keys[b] : a < b;
+    });
+    idx->recs.clear();
+    idx->recs.reserve(d->n_recs);
+    std::vector<uint64_t> ukeys;
+    std::vector<uint32_t> uoff, ucnt;
+    std::vector<uint32_t> tmp;
+    for (uint64_t g = 0; g < d->n_keys;) {
+        uint64_t key = d->keys[korder[g]];
+        tmp.clear();
+        while (g < d->n_keys && d->keys[korder[g]] == key) {
+            uint64_t ki = korder[g++];
+            for (uint64_t j = d->rec_off[ki]; j < d->rec_off[ki + 1]; ++j) tmp.push_back((uint32_t) j);
+        }
+        if (tmp.empty()) continue;
+        // records of one key sorted by (prg, path rank, strand): hits emitted in this order are
+        // already in MinimizerHit::operator< order within one (read, position, prg, strand)
+        std::sort(tmp.begin(), tmp.end(), [&](uint32_t a, uint32_t b) {
+            if (d->rec_prg[a] != d->rec_prg[b]) return d->rec_prg[a] < d->rec_prg[b];
+            if (idx->path_rank[a] != idx->path_rank[b]) return idx->path_rank[a] < idx->path_rank[b];
+            if (d->rec_strand[a] != d->rec_strand[b]) return d->rec_strand[a] < d->rec_strand[b];
+            return a < b;
+        });
+        for (size_t i = 1; i < tmp.size(); ++i) {
+            uint32_t a = tmp[i - 1], b = tmp[i];
+            if (d->rec_prg[a] == d->rec_prg[b] && idx->path_rank[a] == idx->path_rank[b] &&
+                (d->rec_strand[a] != 0) == (d->rec_strand[b] != 0)) {
+                std::ostringstream os;
+                os << "duplicate index record (key " << key << ", prg " << d->rec_prg[a]
+                   << "): MinimizerHits::sort would abort on it";
+                return pmap_fail(PMAP_EDUP, os.str());
+            }
+        }
+        ukeys.push_back(key);
+        uoff.push_back((uint32_t) idx->recs.size());
+        ucnt.push_back((uint32_t) tmp.size());
+        for (uint32_t j : tmp) {
+            PmapRec r;
+            r.prg = d->rec_prg[j];
+            r.knode_strand = d->rec_knode[j] << 1 | (d->rec_strand[j] ? 1u : 0u);
+            r.rank = idx->path_rank[j];
+            r.orig = j;
+            idx->recs.push_back(r);
+        }
+    }
+    idx->n_keys = ukeys.size();
+
+    uint32_t log2cap = 6;
+    while ((1ull << log2cap) < 2 * idx->n_keys) ++log2cap;
+    if (log2cap > 31) return pmap_fail(PMAP_ELIMIT, "minimizer table would exceed 2^31 slots");
+    idx->log2cap = log2cap;
+    const uint32_t cap = 1u << log2cap, capmask = cap - 1;
+    PmapSlot empty{PMAP_EMPTY_KEY, 0, 0};
+    idx->slots.assign(cap, empty);
+    for (size_t i = 0; i < ukeys.size(); ++i) {
+        uint32_t s = pmap_slot_of(ukeys[i], log2cap);
+        while (idx->slots[s].key != PMAP_EMPTY_KEY) s = (s + 1) & capmask;
+        idx->slots[s] = PmapSlot{ukeys[i], uoff[i], ucnt[i]};
+    }
+    return PMAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// text formats
+
+struct Cursor {
+    const char *p, *end;
+    bool more() const { return p < end; }
+    bool read_uint(uint64_t *v) {   // skips anything that is not a digit first
+        while (p < end && !isdigit((unsigned char) *p)) ++p;
+        if (p >= end) return false;
+        uint64_t x = 0;
+        while (p < end && isdigit((unsigned char) *p)) x = x * 10 + (uint64_t) (*p++ - '0');
+        *v = x;
+        return true;
+    }
+};
+
+static bool slurp(const char *path, std::string *out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return false;
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    *out = ss.str();
+    return true;
+}
+
+// MiniRecord text `(prg, N{[s, e)[s, e)...}, knode, strand)` (src/minirecord.cpp:23-38,
+// src/prg/path.cpp:228-249, src/interval.cpp:20-37): the integers in order.
+static bool parse_record(Cursor &c, uint32_t *prg, std::vector<uint32_t> *ivs, std::vector<uint32_t> *ivl,
+                         uint32_t *knode, uint8_t *strand) {
+    uint64_t v, n;
+    if (!c.read_uint(&v)) return false;
+    *prg = (uint32_t) v;
+    if (!c.read_uint(&n)) return false;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t s, e;
+        if (!c.read_uint(&s) || !c.read_uint(&e) || e < s) return false;
+        ivs->push_back((uint32_t) s);
+        ivl->push_back((uint32_t) (e - s));
+    }
+    if (!c.read_uint(&v)) return false;
+    *knode = (uint32_t) v;
+    if (!c.read_uint(&v)) return false;
+    *strand = v != 0;
+    while (c.more() && *c.p != ')') ++c.p;
+    if (c.more()) ++c.p;
+    return true;
+}
+
+extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg, const uint32_t *mpl,
+                               pmap_index_t **out) {
+    std::string text;
+    if (!slurp(idx_path, &text))
+        return pmap_fail(PMAP_EIO, std::string("Unable to open index file ") + idx_path +
+                                       ". Does it exist? Have you run pandora index?");   // src/index.cpp:115
+    Cursor c{text.data(), text.data() + text.size()};
+    std::vector<uint64_t> keys, rec_off{0}, path_off{0};
+    std::vector<uint32_t> rec_prg, rec_knode, ivs, ivl;
+    std::vector<uint8_t> rec_strand;
+    bool first = true;
+    // Index::load (src/index.cpp:86-113): a token starting with a digit is the entry count (first)
+    // or a key followed by its record count; anything else starts a record
+    while (c.more()) {
+        char ch = *c.p;
+        if (isdigit((unsigned char) ch)) {
+            uint64_t v;
+            c.read_uint(&v);
+            if (first) { first = false; continue; }
+            uint64_t cnt;
+            if (!c.read_uint(&cnt)) return pmap_fail(PMAP_EIO, "index file: key without record count");
+            if (!keys.empty()) rec_off.push_back(rec_prg.size());
+            keys.push_back(v);
+        } else if (ch == '(') {
+            if (keys.empty()) return pmap_fail(PMAP_EIO, "index file: record before any key");
+            uint32_t prg, knode;
+            uint8_t strand;
+            if (!parse_record(c, &prg, &ivs, &ivl, &knode, &strand))
+                return pmap_fail(PMAP_EIO, "index file: malformed record");
+            rec_prg.push_back(prg);
+            rec_knode.push_back(knode);
+            rec_strand.push_back(strand);
+            path_off.push_back(ivs.size());
+        } else {
+            ++c.p;
+        }
+    }
+    if (!keys.empty()) rec_off.push_back(rec_prg.size());
+    uint32_t need_prg = 0;
+    for (uint32_t p : rec_prg) need_prg = std::max(need_prg, p + 1);
+    std::vector<uint32_t> mplv(std::max(n_prg, need_prg), 0);
+    if (mpl) std::copy(mpl, mpl + n_prg, mplv.begin());
+    pmap_index_desc_t d;
+    memset(&d, 0, sizeof(d));
+    d.k = k;
+    d.n_keys = keys.size();
+    d.keys = keys.data();
+    d.rec_off = rec_off.data();
+    d.n_recs = rec_prg.size();
+    d.rec_prg = rec_prg.data();
+    d.rec_knode = rec_knode.data();
+    d.rec_strand = rec_strand.data();
+    d.path_off = path_off.data();
+    d.iv_start = ivs.data();
+    d.iv_len = ivl.data();
+    d.n_prg = (uint32_t) mplv.size();
+    d.min_path_length = mplv.data();
+    return pmap_index_create(&d, out);
+}
+
+extern "C" int pmap_index_create(const pmap_index_desc_t *desc, pmap_index_t **out) {
+    if (!desc || !out) return pmap_fail(PMAP_EINVAL, "null argument");
+    pmap_index *idx = new pmap_index();
+    int rc = pmap_index_build_host(desc, idx);
+    if (rc == PMAP_OK) rc = pmap_index_upload(idx);
+    if (rc != PMAP_OK) {
+        pmap_index_release_device(idx);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return PMAP_OK;
+}
+
+extern "C" void pmap_index_destroy(pmap_index_t *idx) {
+    if (!idx) return;
+    pmap_index_release_device(idx);
+    delete idx;
+}
+
+extern "C" int pmap_index_info(const pmap_index_t *idx, pmap_index_info_t *info) {
+    if (!idx || !info) return pmap_fail(PMAP_EINVAL, "null argument");
+    info->k = idx->k;
+    info->n_keys = idx->n_keys;
+    info->n_recs = idx->n_recs;
+    info->n_paths = idx->n_paths;
+    info->table_slots = idx->slots.size();
+    info->device_bytes = idx->device_bytes;
+    info->n_prg = idx->n_prg;
+    return PMAP_OK;
+}
+
+extern "C" int pmap_index_records(const pmap_index_t *idx, uint64_t *key_of_rec, uint32_t *rec_prg,
+                                  uint32_t *rec_knode, uint8_t *rec_strand, uint32_t *path_rank,
+                                  uint64_t *path_off) {
+    if (!idx) return pmap_fail(PMAP_EINVAL, "null argument");
+    size_t n = idx->n_recs;
+    if (key_of_rec) memcpy(key_of_rec, idx->key_of_rec.data(), n * sizeof(uint64_t));
+    if (rec_prg) memcpy(rec_prg, idx->rec_prg.data(), n * sizeof(uint32_t));
+    if (rec_knode) memcpy(rec_knode, idx->rec_knode.data(), n * sizeof(uint32_t));
+    if (rec_strand) memcpy(rec_strand, idx->rec_strand.data(), n);
+    if (path_rank) memcpy(path_rank, idx->path_rank.data(), n * sizeof(uint32_t));
+    if (path_off) memcpy(path_off, idx->path_off.data(), (n + 1) * sizeof(uint64_t));
+    return PMAP_OK;
+}
+
+extern "C" int pmap_index_intervals(const pmap_index_t *idx, uint32_t *iv_start, uint32_t *iv_len,
+                                    uint64_t *n_intervals) {
+    if (!idx) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (n_intervals) *n_intervals = idx->iv_start.size();
+    if (iv_start) memcpy(iv_start, idx->iv_start.data(), idx->iv_start.size() * sizeof(uint32_t));
+    if (iv_len) memcpy(iv_len, idx->iv_len.data(), idx->iv_len.size() * sizeof(uint32_t));
+    return PMAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// KmerGraph::load (src/kmergraph.cpp:716-820) reduced to what min_path_length
+// (src/kmergraph.cpp:664-684) reads: node ids, node paths, out-edges in file order.
+extern "C" int pmap_gfa_min_path_length(const char *gfa_path, uint32_t *out) {
+    std::ifstream f(gfa_path);
+    if (!f.is_open()) return pmap_fail(PMAP_EIO, std::string("Unable to open kmergraph file ") + gfa_path);
+    struct Node {
+        std::vector<uint32_t> ivs, ivl;
+        std::vector<uint32_t> outs;
+        bool present = false;
+    };
+    std::vector<Node> nodes;
+    std::vector<std::pair<uint32_t, uint32_t>> edges;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        if (line[0] == 'S') {
+            // S \t id \t N{[s, e)...} \t FC:i:n \t \t RC:i:n
+            size_t t1 = line.find('\t'), t2 = line.find('\t', t1 + 1), t3 = line.find('\t', t2 + 1);
+            if (t1 == std::string::npos || t2 == std::string::npos)
+                return pmap_fail(PMAP_EIO, "kmergraph GFA: malformed S line");
+            uint32_t id = (uint32_t) strtoul(line.c_str() + t1 + 1, nullptr, 10);
+            std::string ptxt = line.substr(t2 + 1, t3 == std::string::npos ? std::string::npos : t3 - t2 - 1);
+            if (ptxt.empty() || !isdigit((unsigned char) ptxt[0]))   // src/kmergraph.cpp:750
+                return pmap_fail(PMAP_EIO, "kmergraph GFA does not label nodes with their PRG path");
+            Cursor c{ptxt.data(), ptxt.data() + ptxt.size()};
+            uint64_t n;
+            c.read_uint(&n);
+            if (id >= nodes.size()) nodes.resize(id + 1);
+            nodes[id].present = true;
+            for (uint64_t i = 0; i < n; ++i) {
+                uint64_t s, e;
+                if (!c.read_uint(&s) || !c.read_uint(&e) || e < s)
+                    return pmap_fail(PMAP_EIO, "kmergraph GFA: malformed path");
+                nodes[id].ivs.push_back((uint32_t) s);
+                nodes[id].ivl.push_back((uint32_t) (e - s));
+            }
+        } else if (line[0] == 'L') {
+            // L \t from \t + \t to \t + \t 0M
+            std::vector<std::string> tok;
+            std::stringstream ss(line);
+            std::string t;
+            while (std::getline(ss, t, '\t'))
+                if (!t.empty()) tok.push_back(t);
+            if (tok.size() < 5) return pmap_fail(PMAP_EIO, "kmergraph GFA: malformed L line");
+            uint32_t from = (uint32_t) strtoul(tok[1].c_str(), nullptr, 10);
+            uint32_t to = (uint32_t) strtoul(tok[3].c_str(), nullptr, 10);
+            if (tok[2] != tok[4]) std::swap(from, to);   // src/kmergraph.cpp:803-810
+            edges.push_back({from, to});
+        }
+    }
+    for (auto &e : edges) {
+        if (e.first >= nodes.size() || e.second >= nodes.size())
+            return pmap_fail(PMAP_EIO, "kmergraph GFA: edge to unknown node");
+        auto &o = nodes[e.first].outs;
+        if (std::find(o.begin(), o.end(), e.second) == o.end()) o.push_back(e.second);   // add_edge, :177
+    }
+    if (nodes.empty()) { *out = 0; return PMAP_OK; }
+    // sort_topologically (:220-225): by prg::Path::operator<
+    std::vector<uint32_t> sorted(nodes.size());
+    std::iota(sorted.begin(), sorted.end(), 0u);
+    std::sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
+        return path_cmp(nodes[a].ivs.data(), nodes[a].ivl.data(), nodes[a].ivs.size(), nodes[b].ivs.data(),
+                        nodes[b].ivl.data(), nodes[b].ivs.size()) < 0;
+    });
+    // :674-683: len is written by sorted position and read by node id, as the reference does
+    std::vector<uint32_t> len(sorted.size(), 0);
+    for (uint32_t j = (uint32_t) sorted.size() - 1; j != 0; --j)
+        for (uint32_t o : nodes[sorted[j - 1]].outs)
+            if (len[o] + 1 > len[j - 1]) len[j - 1] = len[o] + 1;
+    *out = len[0];
+    return PMAP_OK;
+}
+
+extern "C" float pmap_fraction(float e_rate, uint32_t k) {
+    float x = e_rate * k;
+    return (float) (0.5 / expf(x));
+}

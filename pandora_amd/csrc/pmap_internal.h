@@ -1,0 +1,73 @@
+// Internal definitions shared by the host and device halves of libpandora_amd.
+#ifndef PMAP_INTERNAL_H
+#define PMAP_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pandora_amd.h"
+
+// One open-addressing slot of the minimizer table: 16 bytes, one probe = one slot.
+struct PmapSlot {
+    uint64_t key;   // ~0 = empty
+    uint32_t off;   // first record in the CSR array
+    uint32_t cnt;   // number of records
+};
+
+// One CSR record (a MiniRecord, include/minirecord.h:9-14, with the path replaced by its rank).
+struct PmapRec {
+    uint32_t prg;
+    uint32_t knode_strand;  // knode_id << 1 | strand
+    uint32_t rank;          // rank of (prg, path) in (prg, prg::Path::operator<) order
+    uint32_t orig;          // record index in the caller's arrays
+};
+
+static const uint64_t PMAP_EMPTY_KEY = ~0ULL;
+
+static inline uint32_t pmap_slot_of(uint64_t key, uint32_t log2cap) {
+    return (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> (64 - log2cap));
+}
+
+struct pmap_index {
+    uint32_t k = 0;
+    uint32_t n_prg = 0;
+    uint64_t n_keys = 0, n_recs = 0, n_paths = 0;
+    uint32_t log2cap = 0;
+    // host copies, caller's record numbering
+    std::vector<uint64_t> key_of_rec;
+    std::vector<uint32_t> rec_prg, rec_knode, path_rank;
+    std::vector<uint8_t> rec_strand;
+    std::vector<uint64_t> path_off;
+    std::vector<uint32_t> iv_start, iv_len;
+    std::vector<uint32_t> min_path_length;
+    // host copies of the device structures (kept for checks and rebuilds)
+    std::vector<PmapSlot> slots;
+    std::vector<PmapRec> recs;
+    // device
+    PmapSlot *d_slots = nullptr;
+    PmapRec *d_recs = nullptr;
+    uint32_t *d_thr = nullptr;       // per-prg cluster size threshold of the last pmap_map call
+    uint64_t device_bytes = 0;
+    // parameters d_thr was computed for
+    float thr_fraction = -1.f;
+    uint32_t thr_min_cluster = 0, thr_expected = 0;
+    bool thr_valid = false;
+};
+
+void pmap_set_error(const std::string &msg);
+int pmap_fail(int code, const std::string &msg);
+
+// host side of index construction (pmap_index.cpp); uploads via pmap_index_upload (pmap_device.hip)
+int pmap_index_build_host(const pmap_index_desc_t *desc, pmap_index *idx);
+int pmap_index_upload(pmap_index *idx);
+void pmap_index_release_device(pmap_index *idx);
+
+// (float) threshold of one prg, src/utils.cpp:211-213,219-220
+static inline uint32_t pmap_threshold(uint32_t mpl, uint32_t expected, float fraction, uint32_t min_cluster_size) {
+    uint32_t m = mpl < expected ? mpl : expected;
+    uint32_t length_based = (uint32_t) ((float) m * fraction);
+    return length_based > min_cluster_size ? length_based : min_cluster_size;
+}
+
+#endif

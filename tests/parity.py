@@ -1,0 +1,73 @@
+"""Shared helper: run one batch through the GPU path and through the oracle and compare every
+stage bit for bit (minimizers, sorted hits, kept clusters, filter_clusters survivors)."""
+import numpy as np
+
+import oracle_lib as O
+from pandora_amd import api
+
+UINT32_MAX = 0xFFFFFFFF
+
+
+def gpu_index(si):
+    return api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                            si.iv_start, si.iv_len, si.min_path_length)
+
+
+def oracle_index(si):
+    return O.FlatIndex(si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off, si.iv_start,
+                       si.iv_len)
+
+
+def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size=10, expected_kmers=UINT32_MAX,
+                  first_read_id=0, gidx=None, check_minimizers=True):
+    """Asserts GPU == oracle for one batch; returns (gpu counts, oracle result dict)."""
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n_reads = len(offsets) - 1
+    own = gidx is None
+    if own:
+        gidx = gpu_index(si)
+    rd = api.Reads(bases, offsets, first_read_id)
+    res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers)
+    cn = res.counts()
+    ids = np.arange(first_read_id, first_read_id + n_reads, dtype=np.uint32)
+    orc = O.oracle_map(oracle_index(si), bases, offsets, ids, w, k, max_diff, fraction, min_cluster_size,
+                       expected_kmers, si.min_path_length)
+    assert orc["n_dup_hits"] == 0
+
+    # minimizer set per read (Seq::sketch)
+    assert cn["n_minimizers"] == len(orc["mini_kmer"])
+    if check_minimizers:
+        gm = res.minimizers()
+        so = orc["sketch_off"]
+        oread = np.repeat(ids, np.diff(so).astype(np.int64))
+        np.testing.assert_array_equal(gm["read"], oread)
+        np.testing.assert_array_equal(gm["pos"], orc["mini_pos"])
+        np.testing.assert_array_equal(gm["kmer"], orc["mini_kmer"])
+        np.testing.assert_array_equal(gm["strand"], orc["mini_strand"])
+
+    # MinimizerHits in MinimizerHit::operator< order
+    gh = res.hits(sorted=True)
+    assert cn["n_hits"] == len(orc["hit_read"])
+    for a, b in (("read", "hit_read"), ("prg", "hit_prg"), ("fwd", "hit_fwd"), ("pos", "hit_pos"),
+                 ("rec", "hit_rec")):
+        np.testing.assert_array_equal(gh[a], orc[b], err_msg=a)
+
+    # clusters kept by define_clusters, then clusterComp order and filter_clusters
+    assert cn["n_clusters_all"] == orc["n_all_clusters"]
+    gc = res.clusters()
+    assert cn["n_clusters"] == len(orc["cl_size"])
+    order, alive = api.filter_clusters(gc)
+    o = order.astype(np.int64)
+    np.testing.assert_array_equal(gc["begin"][o], orc["cl_begin"])
+    np.testing.assert_array_equal(gc["size"][o], orc["cl_size"])
+    np.testing.assert_array_equal(gc["read"][o], orc["cl_read"])
+    np.testing.assert_array_equal(gc["prg"][o], orc["cl_prg"])
+    np.testing.assert_array_equal(gc["fwd"][o], orc["cl_fwd"])
+    np.testing.assert_array_equal(gc["first_pos"][o], orc["cl_first_pos"])
+    np.testing.assert_array_equal(gc["last_pos"][o], orc["cl_last_pos"])
+    np.testing.assert_array_equal(alive, orc["cl_alive"])
+    res.close()
+    rd.close()
+    if own:
+        gidx.close()
+    return cn, orc

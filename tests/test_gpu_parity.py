@@ -1,0 +1,168 @@
+"""GPU parity tests: every stage of the HIP path against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pandora_amd import api, synth
+from parity import compare_batch, gpu_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_world(seed, w, k, n_loci=40, n_reads=60, split_paths=0.0, mean_len=3000, e_rate=0.08):
+    rng = np.random.default_rng(seed)
+    loci = synth.make_loci(n_loci, rng, dup_frac=0.1)
+    si = synth.build_index(loci, w, k, rng=rng, split_paths=split_paths)
+    genome = synth.make_genome(loci, rng)
+    bases, off = synth.simulate_reads(genome, n_reads, rng, mean_len=mean_len, e_rate=e_rate, n_frac=0.05,
+                                      short_frac=0.05)
+    return si, bases, off
+
+
+def test_nanopore_small(gpu):
+    si, bases, off = _small_world(1, 14, 15)
+    cn, orc = compare_batch(si, bases, off, 14, 15, 250, api.fraction(0.11, 15))
+    assert cn["n_hits"] > 1000 and cn["n_clusters"] > 10
+
+
+def test_split_paths_and_first_read_id(gpu):
+    si, bases, off = _small_world(2, 14, 15, split_paths=0.5)
+    cn, _ = compare_batch(si, bases, off, 14, 15, 250, api.fraction(0.11, 15), first_read_id=1000)
+    assert cn["n_clusters"] > 0
+
+
+@pytest.mark.parametrize("w,k", [(1, 15), (5, 15), (10, 11), (14, 15), (19, 19), (31, 31), (7, 16), (12, 21),
+                                 (1, 31), (14, 3), (3, 5)])
+def test_wk_grid(gpu, w, k):
+    si, bases, off = _small_world(10 + w + 100 * k, w, k, n_loci=12, n_reads=25, mean_len=1500, e_rate=0.03)
+    compare_batch(si, bases, off, w, k, 100, api.fraction(0.05, k), min_cluster_size=3)
+
+
+def test_low_complexity_ties(gpu):
+    """Homopolymers and short repeats: long runs of equal hashes, every tie must be kept."""
+    rng = np.random.default_rng(5)
+    reads = [b"A" * 500, b"AC" * 300, b"ACG" * 200, b"T" * 40 + b"ACGT" * 50 + b"G" * 100,
+             bytes(synth.random_dna(50, rng)) * 20, b"AAAAAAAAAAAAAAAAAAAAC" * 30]
+    loci = [np.frombuffer(r, np.uint8).copy() for r in reads[:4]]
+    for w, k in [(1, 3), (2, 3), (5, 4), (12, 5), (14, 15), (8, 8)]:
+        si = synth.build_index(loci, w, k)
+        bases, off = O.pack_reads(reads)
+        compare_batch(si, bases, off, w, k, 50, api.fraction(0.01, k), min_cluster_size=1)
+
+
+def test_edge_reads(gpu):
+    """Lengths around w+k-1, non-ACGT letters, lower case, raw 0..3 bytes, empty reads."""
+    rng = np.random.default_rng(6)
+    w, k = 14, 15
+    locus = synth.random_dna(400, rng)
+    si = synth.build_index([locus], w, k)
+    body = bytes(locus)
+    reads = [
+        body[:w + k - 2],            # one base too short: no sketch
+        body[:w + k - 1],            # exactly one window
+        body[:w + k],
+        b"",
+        body[:200].lower(),
+        body[:100] + b"N" + body[101:300],
+        body[:100] + b"U" + body[101:300],
+        bytes(synth._CODE[np.frombuffer(body[:300], np.uint8)]),   # bytes 0,1,2,3 are valid letters
+        body[50:51],
+        body,
+        b"",
+        body[:16], body[:17], body[:31], body[:32], body[:33],     # word-boundary lengths
+        bytes(synth.revcomp(locus)),
+    ]
+    bases, off = O.pack_reads(reads)
+    cn, orc = compare_batch(si, bases, off, w, k, 250, api.fraction(0.11, k), min_cluster_size=1)
+    so = orc["sketch_off"]
+    assert so[1] - so[0] == 0 and so[2] - so[1] >= 1
+    assert so[6] - so[5] == 0 and so[7] - so[6] == 0
+
+
+def test_illumina_thresholds(gpu):
+    """150 bp reads: w=1 dense sketch where the reference's own threshold rejects every cluster
+    (expected_kmers = 300 -> threshold 147 > 136 k-mers per read), and w=14 where clusters survive."""
+    rng = np.random.default_rng(8)
+    loci = synth.make_loci(30, rng)
+    genome = synth.make_genome(loci, rng)
+    bases, off = synth.simulate_reads(genome, 400, rng, fixed_len=150, e_rate=0.001)
+    k = 15
+    for w in (1, 14):
+        si = synth.build_index(loci, w, k)
+        frac = api.fraction(0.001, k)
+        cn, orc = compare_batch(si, bases, off, w, k, 2 * k + 1, frac, 10, expected_kmers=150 * 2 // w)
+        if w == 1:
+            assert cn["n_hits"] > 10000 and cn["n_clusters"] == 0
+        else:
+            assert cn["n_clusters"] > 0
+
+
+def test_large_segment_and_reuse(gpu):
+    """One read with far more hits than the sort kernel's LDS chunk, and result reuse across calls."""
+    rng = np.random.default_rng(9)
+    w, k = 1, 9
+    locus = synth.random_dna(6000, rng)
+    si = synth.build_index([locus, locus[1000:4000].copy()], w, k)
+    reads = [bytes(locus), bytes(locus[:3000]), bytes(synth.revcomp(locus))]
+    bases, off = O.pack_reads(reads)
+    cn, _ = compare_batch(si, bases, off, w, k, 20, api.fraction(0.01, k), min_cluster_size=2)
+    assert cn["n_hits"] > 3 * 2048
+    gidx = gpu_index(si)
+    rd = api.Reads(bases, off)
+    res = api.map_reads(gidx, rd, w, k, 20, 0.3, 2)
+    first = res.hits()
+    small = api.Reads.from_list([bytes(locus[:500])])
+    res = api.map_reads(gidx, small, w, k, 20, 0.3, 2, result=res)
+    assert res.counts()["n_hits"] < len(first["read"])
+    res = api.map_reads(gidx, rd, w, k, 20, 0.3, 2, result=res)
+    again = res.hits()
+    for f in first:
+        np.testing.assert_array_equal(first[f], again[f])
+
+
+def test_empty_batches(gpu):
+    rng = np.random.default_rng(11)
+    si = synth.build_index([synth.random_dna(300, rng)], 14, 15)
+    gidx = gpu_index(si)
+    for reads in ([], [b""], [b"ACGT"], [b"N" * 100]):
+        rd = api.Reads.from_list(reads)
+        res = api.map_reads(gidx, rd, 14, 15, 250, 0.1)
+        c = res.counts()
+        assert c["n_minimizers"] == 0 and c["n_hits"] == 0 and c["n_clusters"] == 0
+    # reads that sketch but hit nothing
+    rd = api.Reads.from_list([bytes(synth.random_dna(2000, rng))])
+    c = api.map_reads(gidx, rd, 14, 15, 250, 0.1).counts()
+    assert c["n_minimizers"] > 0 and c["n_hits"] == 0 and c["n_clusters"] == 0
+
+
+def test_stage_entry_points(gpu):
+    si, bases, off = _small_world(3, 14, 15, n_loci=10, n_reads=10)
+    gidx = gpu_index(si)
+    rd = api.Reads(bases, off)
+    r1 = api.map_reads(gidx, rd, 14, 15, 250, 0.1, last_stage=api.STAGE_SKETCH)
+    c1 = r1.counts()
+    assert c1["n_minimizers"] > 0 and c1["n_hits"] == 0
+    r2 = api.map_reads(gidx, rd, 14, 15, 250, 0.1, last_stage=api.STAGE_HITS)
+    c2 = r2.counts()
+    assert c2["n_hits"] > 0 and c2["n_clusters_all"] == 0
+    # emission order: (read, position) ascending
+    h = r2.hits(sorted=False)
+    key = h["read"].astype(np.int64) * (1 << 32) + h["pos"]
+    assert (np.diff(key) >= 0).all()
+
+
+def test_errors(gpu):
+    rng = np.random.default_rng(12)
+    si = synth.build_index([synth.random_dna(300, rng)], 14, 15)
+    gidx = gpu_index(si)
+    rd = api.Reads.from_list([b"ACGT" * 100])
+    with pytest.raises(api.PmapError):
+        api.map_reads(gidx, rd, 14, 16, 250, 0.1)       # k differs from the index
+    with pytest.raises(api.PmapError):
+        api.map_reads(gidx, rd, 0, 15, 250, 0.1)        # w = 0 (the reference asserts w != 0)
+    # duplicate record: MinimizerHits::sort would abort in the reference
+    with pytest.raises(api.PmapError) as e:
+        api.Index.create(15, [5], [0, 2], [0, 0], [1, 2], [1, 1], [0, 1, 2], [3, 3], [15, 15], [4])
+    assert e.value.code == 5
+    with pytest.raises(api.PmapError):
+        api.Index.create(32, [], [0], [], [], [], [0], [], [], [])
