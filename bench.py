@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the read -> PRG minimizer path (sketch + probe + sort + cluster) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the whole device path (pmap_map: sketch, probe/emit, sort, cluster cut) over
+one batch of synthetic reads that is already resident in HBM (2-bit packed).  At N > 1 every rank
+maps its own, equally sized batch against a replicated index (reads shard, no collective on the data
+path); the value is the total number of read bases all ranks mapped per second.  Rank 0 prints one
+JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+# kernels of each phase (names of pmap_kernel_name)
+PHASES = {
+    "sketch": ["sketch_flags", "sketch_scan", "sketch_emit"],
+    "probe": ["probe", "hit_scan", "scatter", "seg_bounds"],
+    "sort": ["sort_rank"],
+    "cluster": ["cluster_flags", "cluster_scan", "cluster_starts", "cluster_table", "kept_scan", "kept_gather"],
+}
+
+
+def algorithmic_bytes(cn, n_prg, n_reads_batch):
+    """Algorithmic bytes of each phase for one launch of the path over one batch:
+    B read bases, M minimizers, H hits, C clusters.
+      sketch   B/4 (2-bit packed read) + 16 M (u64 hash + u32 position + u32 read/strand written)
+      probe    2 (16 M + 16 M) (minimizer re-read + one 16-byte slot per probe, count and scatter pass)
+               + H (16 + 20) (16-byte record read, 20-byte hit written)
+      sort     2 * 20 * H * P, P = 8-bit passes over the (read, prg, strand) key
+      cluster  20 H read + 4 H flag/id written + 28 C
+    """
+    B, M, H, C = cn["n_bases"], cn["n_minimizers"], cn["n_hits"], cn["n_clusters_all"]
+    bits = max(1, int(np.ceil(np.log2(max(n_reads_batch, 2))))) + max(1, int(np.ceil(np.log2(max(n_prg, 2))))) + 1
+    P = int(np.ceil(bits / 8))
+    return {
+        "sketch": B / 4 + 16 * M,
+        "probe": 2 * (16 * M + 16 * M) + H * 36,
+        "sort": 2 * 20 * H * P,
+        "cluster": 20 * H + 4 * H + 28 * C,
+    }, P
+
+
+def cpu_baseline(si, bases, offsets, prm, fraction, budget_s=12.0):
+    """The oracle (plain-C restatement of the reference path, one thread) timed on a bounded sample
+    of the same reads: chunks of 250 reads until the time budget is used."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    oi = O.FlatIndex(si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off, si.iv_start,
+                     si.iv_len)
+    n_reads = len(offsets) - 1
+    done_bases, done_reads, hits, t_used = 0, 0, 0, 0.0
+    chunk = 250
+    while done_reads < n_reads and t_used < budget_s:
+        a, b = done_reads, min(done_reads + chunk, n_reads)
+        sub_off = offsets[a:b + 1]
+        ids = np.arange(a, b, dtype=np.uint32)
+        sub = bases[int(sub_off[0]):int(sub_off[-1])]
+        t0 = time.perf_counter()
+        r = O.oracle_map(oi, sub, sub_off - sub_off[0], ids, prm["w"], prm["k"], prm["max_diff"], fraction,
+                         prm["min_cluster_size"], 0xFFFFFFFF, si.min_path_length)
+        t_used += time.perf_counter() - t0
+        done_bases += int(sub_off[-1] - sub_off[0])
+        hits += len(r["hit_read"])
+        done_reads = b
+    return {"value": done_bases / t_used, "unit": "bases/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads (%d bases, %d hits) of the same workload, oracle/liboracle.so, %.1f s"
+                      % (done_reads, done_bases, hits, t_used),
+            "hits_per_s": hits / t_used}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="nanopore_1k")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import pandora_amd
+    from pandora_amd import api, synth
+    pandora_amd.init(local_rank)
+
+    # same index on every rank (replicated), a different shard of reads per rank
+    si, bases, offsets, prm = synth.workload(args.workload, seed=1, scale=args.scale, shard=rank)
+    fraction = api.fraction(prm["e_rate"], prm["k"])
+    expected = 0xFFFFFFFF
+    if prm["illumina"]:
+        expected = 150 * 2 // prm["w"]
+    gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                            si.iv_start, si.iv_len, si.min_path_length)
+    t0 = time.perf_counter()
+    reads = api.Reads(bases, offsets)
+    upload_s = time.perf_counter() - t0
+
+    def step(res, profile):
+        return api.map_reads(gidx, reads, prm["w"], prm["k"], prm["max_diff"], fraction, prm["min_cluster_size"],
+                             expected, profile=profile, result=res)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step(res, 0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    kernel_ms = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(res, 2)    # per-kernel HIP events on the library's stream, inside the timed region
+        for name, ms in res.kernel_ms().items():
+            kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
+    sync()
+    elapsed = time.perf_counter() - t0
+    cn = res.counts()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(cn["n_bases"]), float(cn["n_hits"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_bases, total_hits = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        kernel_ms = {k: v / steps for k, v in kernel_ms.items()}
+        algo, P = algorithmic_bytes(cn, si.n_prg, cn["n_reads"])
+        phases = {}
+        for ph, ks in PHASES.items():
+            ms = sum(kernel_ms.get(k, 0.0) for k in ks)
+            phases[ph] = {"ms": ms, "algorithmic_bytes": algo[ph],
+                          "GBps": (algo[ph] / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
+                          "kernels": {k: kernel_ms.get(k, 0.0) for k in ks}}
+        dom = max(phases, key=lambda p: phases[p]["ms"])
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "%s phase (%s)" % (dom, "+".join(PHASES[dom])),
+                    "achieved": phases[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": phases[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                    "ms_per_launch": phases[dom]["ms"], "algorithmic_bytes_per_launch": algo[dom]}
+        out = {
+            "metric": "read bases mapped/sec (sketch+probe+cluster)",
+            "value": total_bases * args.steps / elapsed,
+            "unit": "bases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if prm["k"] <= 15 else "u64",
+            "data": "synthetic",
+            "config": {"workload": "%s: 1000-locus synthetic PRG index, %d reads/GPU (%d bases/GPU), w=%d k=%d"
+                                   % (args.workload, cn["n_reads"], cn["n_bases"], prm["w"], prm["k"]),
+                       "reads_per_gpu": cn["n_reads"], "bases_per_gpu": cn["n_bases"],
+                       "minimizers_per_gpu": cn["n_minimizers"], "hits_per_gpu": cn["n_hits"],
+                       "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],
+                       "index_keys": int(len(si.keys)), "index_records": int(len(si.rec_prg)),
+                       "parallelism": "reads sharded over %d GPU(s), index replicated" % world},
+            "hits_per_s": total_hits * args.steps / elapsed,
+            "roofline": roofline,
+            "phases": phases,
+            "sort_passes_P": P,
+            "upload_and_encode_s": upload_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(si, bases, offsets, prm, fraction)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,67 +166,65 @@ def make_genome(loci, rng, spacer=(200, 2000)):
     return np.concatenate(parts)
 
 
-def _with_errors(seq, rng, e_rate):
-    """Substitutions, insertions and deletions, a third each."""
-    n = len(seq)
-    u = rng.random(n)
-    sub = u < e_rate / 3
-    ins = (u >= e_rate / 3) & (u < 2 * e_rate / 3)
-    dele = (u >= 2 * e_rate / 3) & (u < e_rate)
-    seq = seq.copy()
-    seq[sub] = random_dna(int(sub.sum()), rng)
-    reps = np.ones(n, np.int64)
-    reps[ins] = 2
-    reps[dele] = 0
-    out = np.repeat(seq, reps)
-    # the first copy of every doubled base becomes the inserted random base
-    starts = np.cumsum(reps) - reps
-    out[starts[ins]] = random_dna(int(ins.sum()), rng)
-    return out
-
-
 def simulate_reads(genome, n_reads, rng, mean_len=10000, sigma=0.5, e_rate=0.11, fixed_len=None, n_frac=0.001,
                    short_frac=0.001, short_len=20):
     """Reads sampled uniformly from the genome.  fixed_len=150 gives Illumina-style reads (substitutions
     only).  n_frac of the reads get one 'N' (the reference drops such reads, src/seq.cpp:49-53),
     short_frac are shorter than any w+k-1."""
     G = len(genome)
-    reads = []
+    if n_reads == 0:
+        return np.zeros(0, np.uint8), np.zeros(1, np.uint64)
     mu = np.log(mean_len) - sigma * sigma / 2
-    for _ in range(n_reads):
-        if fixed_len:
-            L = fixed_len
-        else:
-            L = int(min(max(rng.lognormal(mu, sigma), 200), G - 1))
-        if rng.random() < short_frac:
-            L = short_len
-        s = int(rng.integers(0, G - L))
-        r = genome[s:s + L]
-        if rng.random() < 0.5:
-            r = revcomp(r)
-        if fixed_len:
-            r = r.copy()
-            sub = rng.random(L) < e_rate
-            r[sub] = random_dna(int(sub.sum()), rng)
-        else:
-            r = _with_errors(r, rng, e_rate)
-        if rng.random() < n_frac and len(r):
-            r = r.copy()
-            r[int(rng.integers(0, len(r)))] = ord("N")
-        reads.append(r)
-    lens = np.array([len(r) for r in reads], np.uint64)
-    offsets = np.zeros(n_reads + 1, np.uint64)
+    if fixed_len:
+        lens = np.full(n_reads, fixed_len, np.int64)
+    else:
+        lens = np.clip(rng.lognormal(mu, sigma, n_reads), 200, G - 1).astype(np.int64)
+    lens[rng.random(n_reads) < short_frac] = short_len
+    starts = (rng.random(n_reads) * (G - lens)).astype(np.int64)
+    flip = rng.random(n_reads) < 0.5
+    gcode = _CODE[genome]
+    parts = []
+    for s, L, f in zip(starts, lens, flip):
+        c = gcode[s:s + L]
+        parts.append(3 - c[::-1] if f else c)
+    clean = _ACGT[np.concatenate(parts)]
+    offsets = np.zeros(n_reads + 1, np.int64)
     offsets[1:] = np.cumsum(lens)
-    bases = np.concatenate(reads) if reads else np.zeros(0, np.uint8)
-    return bases, offsets
+    n = len(clean)
+    u = rng.random(n, dtype=np.float32)
+    if fixed_len:
+        sub = u < e_rate
+        clean[sub] = random_dna(int(sub.sum()), rng)
+        bases = clean
+    else:
+        # substitutions, insertions and deletions, a third each, over the whole batch at once
+        sub = u < e_rate / 3
+        ins = (u >= e_rate / 3) & (u < 2 * e_rate / 3)
+        dele = (u >= 2 * e_rate / 3) & (u < e_rate)
+        clean[sub] = random_dna(int(sub.sum()), rng)
+        reps = np.ones(n, np.int8)
+        reps[ins] = 2
+        reps[dele] = 0
+        bases = np.repeat(clean, reps)
+        new_end = np.concatenate([[0], np.cumsum(reps, dtype=np.int64)])
+        # the first copy of every doubled base becomes the inserted random base
+        bases[new_end[:-1][ins]] = random_dna(int(ins.sum()), rng)
+        offsets = new_end[offsets]
+    # one 'N' in a few reads
+    for r in np.nonzero(rng.random(n_reads) < n_frac)[0]:
+        if offsets[r + 1] > offsets[r]:
+            bases[int(rng.integers(offsets[r], offsets[r + 1]))] = ord("N")
+    return bases, offsets.astype(np.uint64)
 
 
-def workload(name, seed=1, scale=1.0):
+def workload(name, seed=1, scale=1.0, shard=0):
     """Named synthetic workloads.  Returns (SynthIndex, bases, offsets, params dict).
 
     nanopore_1k   1 000 loci, 10 000 reads of ~10 kb at 11 % error, w=14 k=15 (scale multiplies reads)
     illumina_1k   1 000 loci, 150 bp reads at 0.1 % substitutions, w=14 k=15, illumina thresholds
     illumina_w1   the same with w=1 (dense minimizers; the reference's threshold rejects every cluster)
+
+    `shard` selects an independent batch of reads over the same index and genome (one per GPU rank).
     """
     rng = np.random.default_rng(seed)
     if name == "nanopore_1k":
@@ -234,7 +232,7 @@ def workload(name, seed=1, scale=1.0):
         loci = make_loci(n_loci, rng)
         idx = build_index(loci, w, k)
         genome = make_genome(loci, np.random.default_rng(seed + 1))
-        bases, off = simulate_reads(genome, n_reads, np.random.default_rng(seed + 2))
+        bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 2, shard]))
         prm = dict(w=w, k=k, max_diff=250, e_rate=0.11, min_cluster_size=10, illumina=False)
     elif name in ("illumina_1k", "illumina_w1"):
         w = 1 if name == "illumina_w1" else 14
@@ -242,7 +240,7 @@ def workload(name, seed=1, scale=1.0):
         loci = make_loci(n_loci, rng)
         idx = build_index(loci, w, k)
         genome = make_genome(loci, np.random.default_rng(seed + 1))
-        bases, off = simulate_reads(genome, n_reads, np.random.default_rng(seed + 3), fixed_len=150, e_rate=0.001)
+        bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 3, shard]), fixed_len=150, e_rate=0.001)
         prm = dict(w=w, k=k, max_diff=2 * k + 1, e_rate=0.001, min_cluster_size=10, illumina=True)
     else:
         raise ValueError(name)
