@@ -66,9 +66,12 @@ typedef struct {
 /* Replaces the unordered_map behind Index::minhash / Index::add_record
  * (src/index.cpp:20-37): builds the open-addressing table + CSR record array +
  * per-(prg,path) ranks (order of prg::Path::operator<, src/prg/path.cpp:166-183)
- * and uploads them.  Record indices reported by results are indices into the
- * caller's arrays. */
+ * on the host; they are uploaded to HBM by the first pmap_map call that uses
+ * the index (or by pmap_index_upload_now).  Record indices reported by results
+ * are indices into the caller's arrays. */
 int pmap_index_create(const pmap_index_desc_t *desc, pmap_index_t **out);
+/* Uploads the table and records to HBM now (e.g. outside a timed region). */
+int pmap_index_upload_now(pmap_index_t *idx);
 
 /* Replaces Index::load (src/index.cpp:75-124): parses the reference's text
  * `.idx` format.  min_path_length as above (n_prg entries). */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pmap_last_error": (C.c_char_p, []),
     "pmap_init": (C.c_int, [C.c_int]),
     "pmap_index_create": (C.c_int, [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]),
+    "pmap_index_upload_now": (C.c_int, [C.c_void_p]),
     "pmap_index_load": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_void_p)]),
     "pmap_gfa_min_path_length": (C.c_int, [C.c_char_p, u32p]),
     "pmap_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),

@@ -73,6 +73,9 @@ class Index:
         _check(lib.pmap_index_load(str(idx_path).encode(), k, len(mpl), _p(mpl, u32p), C.byref(h)))
         return Index(h)
 
+    def upload(self):
+        _check(_lib.load().pmap_index_upload_now(self._h))
+
     def info(self):
         i = _lib.IndexInfo()
         _check(_lib.load().pmap_index_info(self._h, C.byref(i)))

@@ -674,6 +674,7 @@ struct pmap_result {
 int pmap_index_upload(pmap_index *idx) {
     int rc = ensure_init();
     if (rc) return rc;
+    if (idx->d_slots) return PMAP_OK;
     size_t sb = idx->slots.size() * sizeof(PmapSlot), rb = (idx->recs.size() + 1) * sizeof(PmapRec);
     HIP_TRY(hipMalloc((void **) &idx->d_slots, sb));
     HIP_TRY(hipMalloc((void **) &idx->d_recs, rb));
@@ -682,6 +683,11 @@ int pmap_index_upload(pmap_index *idx) {
         HIP_TRY(hipMemcpy(idx->d_recs, idx->recs.data(), idx->recs.size() * sizeof(PmapRec), hipMemcpyHostToDevice));
     idx->device_bytes = sb + rb;
     return PMAP_OK;
+}
+
+extern "C" int pmap_index_upload_now(pmap_index_t *idx) {
+    if (!idx) return pmap_fail(PMAP_EINVAL, "null argument");
+    return pmap_index_upload(idx);
 }
 
 void pmap_index_release_device(pmap_index *idx) {
@@ -840,6 +846,7 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
     if (rc) return rc;
     if (!idx || !rd || !prm || !result) return pmap_fail(PMAP_EINVAL, "null argument");
     if (prm->k != idx->k) return pmap_fail(PMAP_EINVAL, "k differs from the k the index was built with");
+    if (!idx->d_slots && (rc = pmap_index_upload(const_cast<pmap_index *>(idx)))) return rc;
     if (prm->w < 1 || prm->w > (uint32_t) SK_HALO + 1)
         return pmap_fail(PMAP_EINVAL, "w must be in [1,65]");
     pmap_result *res = *result;

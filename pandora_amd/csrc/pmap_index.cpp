@@ -270,8 +270,8 @@ extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg,
 extern "C" int pmap_index_create(const pmap_index_desc_t *desc, pmap_index_t **out) {
     if (!desc || !out) return pmap_fail(PMAP_EINVAL, "null argument");
     pmap_index *idx = new pmap_index();
+    // host structures only: the table and records go to HBM on the first pmap_map call
     int rc = pmap_index_build_host(desc, idx);
-    if (rc == PMAP_OK) rc = pmap_index_upload(idx);
     if (rc != PMAP_OK) {
         pmap_index_release_device(idx);
         delete idx;

@@ -1,0 +1,126 @@
+"""pangraph_from_read_file through the C ABI: the reference's own expectations for read2.fa /
+read2.fq, and file-level parity with the oracle (reader quirks, read-id assignment, coverage stop,
+batch-size invariance, filter_clusters, add_node sequence)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_cases as RC
+from pandora_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(os.path.dirname(__file__), "golden", "ref_fixtures")
+
+
+def _index_from_records(records, mpl, k):
+    fi = O.FlatIndex.from_records(records)
+    return fi, api.Index.create(k, fi.keys, fi.rec_off, fi.rec_prg, fi.rec_knode, fi.rec_strand, fi.path_off,
+                                fi.iv_start, fi.iv_len, mpl)
+
+
+@pytest.mark.parametrize("fname", ["read2.fa", "read2.fq"])
+def test_reference_pangraph_from_read_file(gpu, fname):
+    # test/utils_test.cpp:708-944: nodes 0, 1, 2, 3 appear
+    case = RC.PANGRAPH_FROM_READ_FILE
+    fi, idx = _index_from_records(case["records"], RC.case_mpl(case), 3)
+    pg = api.pangraph_from_read_file(os.path.join(FIX, fname), idx, 1, 3, 1, 0.1, 1)
+    assert set(pg.nodes()) == case["expected_nodes"]
+    assert set(pg.reads()) == {0, 1}          # read2 and read2_prime
+
+
+def _expected_from_oracle(si, path_bytes, w, k, max_diff, e_rate, min_cluster_size, genome_size, illumina, max_covg):
+    reads = O.fastaq_iterate(path_bytes)
+    bases, off = O.pack_reads([r for _, r in reads])
+    used, take, ids, covg, exp = O.read_loop(bases, off, w, k, genome_size, max_covg, illumina)
+    # untaken reads produce nothing: blank them so one oracle call covers the file
+    keep = [reads[i][1] if take[i] else "" for i in range(len(reads))]
+    kb, ko = O.pack_reads(keep)
+    fi = O.FlatIndex(si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off, si.iv_start,
+                     si.iv_len)
+    frac = O.lib().orc_fraction(e_rate, k)
+    res = O.oracle_map(fi, kb, ko, ids, w, k, max_diff, frac, min_cluster_size, exp, si.min_path_length)
+    return res, covg, fi
+
+
+def _check_pangraph(pg, res, covg):
+    alive = res["cl_alive"].astype(bool)
+    calls = pg.calls()
+    np.testing.assert_array_equal(calls["prg"], res["cl_prg"][alive])
+    np.testing.assert_array_equal(calls["read"], res["cl_read"][alive])
+    np.testing.assert_array_equal(calls["size"], res["cl_size"][alive])
+    np.testing.assert_array_equal(calls["fwd"], res["cl_fwd"][alive])
+    assert pg.covg == covg
+    # node coverage = number of add_node calls per prg; read node lists drop immediate repeats
+    exp_covg, exp_reads = {}, {}
+    for p, r, f in zip(res["cl_prg"][alive], res["cl_read"][alive], res["cl_fwd"][alive]):
+        exp_covg[int(p)] = exp_covg.get(int(p), 0) + 1
+        lst = exp_reads.setdefault(int(r), [])
+        if not lst or lst[-1] != (int(p), int(f)):
+            lst.append((int(p), int(f)))
+    assert pg.nodes() == exp_covg
+    assert pg.reads() == exp_reads
+    # Read::hits = the hits of every surviving cluster
+    exp_hits = set()
+    for b, s in zip(res["cl_begin"][alive], res["cl_size"][alive]):
+        for i in range(int(b), int(b) + int(s)):
+            exp_hits.add((int(res["hit_read"][i]), int(res["hit_prg"][i]), int(res["hit_pos"][i]),
+                          int(res["hit_rec"][i]), int(res["hit_fwd"][i])))
+    h = pg.hits()
+    got = list(zip(h["read"].tolist(), h["prg"].tolist(), h["pos"].tolist(), h["rec"].tolist(), h["fwd"].tolist()))
+    assert len(got) == len(exp_hits) and set(got) == exp_hits
+    return len(calls["prg"])
+
+
+def _write_fastq(path, bases, off, rng, blank_tail=True):
+    with open(path, "wb") as f:
+        for i in range(len(off) - 1):
+            seq = bytes(bases[int(off[i]):int(off[i + 1])])
+            if i % 3 == 0:
+                f.write(b">r%d\n" % i)
+                for j in range(0, len(seq), 70):     # multi-line FASTA record
+                    f.write(seq[j:j + 70] + b"\n")
+            else:
+                f.write(b"@r%d\n" % i + seq + b"\n+\n" + b"@" * len(seq) + b"\n")
+        if blank_tail:
+            f.write(b"\n\n")                          # the reference maps the last read again per blank line
+
+
+def test_file_parity_nanopore(gpu, tmp_path):
+    rng = np.random.default_rng(21)
+    loci = synth.make_loci(25, rng, dup_frac=0.1)
+    si = synth.build_index(loci, 14, 15)
+    genome = synth.make_genome(loci, rng)
+    bases, off = synth.simulate_reads(genome, 80, rng, mean_len=2500, e_rate=0.06, n_frac=0.05, short_frac=0.05)
+    p = tmp_path / "reads.fq"
+    _write_fastq(p, bases, off, rng)
+    idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                           si.iv_start, si.iv_len, si.min_path_length)
+    res, covg, _ = _expected_from_oracle(si, p.read_bytes(), 14, 15, 250, 0.11, 10, 5000, False, 300)
+    for batch in (0, 20000, 3000):                    # batch size must not change anything
+        pg = api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000, False, False, 300, batch_bases=batch)
+        n = _check_pangraph(pg, res, covg)
+        assert n > 20
+
+
+def test_file_parity_coverage_stop_and_illumina(gpu, tmp_path):
+    rng = np.random.default_rng(22)
+    loci = synth.make_loci(10, rng)
+    si = synth.build_index(loci, 14, 15)
+    genome = synth.make_genome(loci, rng)
+    bases, off = synth.simulate_reads(genome, 300, rng, fixed_len=150, e_rate=0.002, n_frac=0.02)
+    p = tmp_path / "ill.fa"
+    _write_fastq(p, bases, off, rng, blank_tail=False)
+    idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                           si.iv_start, si.iv_len, si.min_path_length)
+    # genome_size 1000, max_covg 20: stops after ~21 kb of sketched reads
+    res, covg, _ = _expected_from_oracle(si, p.read_bytes(), 14, 15, 31, 0.001, 2, 1000, True, 20)
+    pg = api.pangraph_from_read_file(p, idx, 14, 15, 31, 0.001, 2, 1000, True, False, 20, batch_bases=5000)
+    n = _check_pangraph(pg, res, covg)
+    assert covg == 21 and 0 < n and max(pg.reads()) < 200
+    with pytest.raises(api.PmapError):
+        api.pangraph_from_read_file(p, idx, 14, 15, 31, 0.001, 2, 1000, True, True, 20)      # clean=true
+    with pytest.raises(api.PmapError) as e:
+        api.pangraph_from_read_file(tmp_path / "missing.fa", idx, 14, 15, 31, 0.001)
+    assert e.value.code == 3

@@ -1,0 +1,275 @@
+"""CPU-side checks of libpandora_amd.so that need no GPU: exported symbols, index construction
+(table, CSR, path ranks, text parser), the FASTA/FASTQ reader, min_path_length, clusterComp +
+filter_clusters, read sharding under gloo."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_cases as RC
+from pandora_amd import _lib, api, sharding, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pandora_amd.h")).read()
+    declared = set(re.findall(r"\b(pmap_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pmap_index_desc_t"}
+    lib = _lib.load()
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.PmapError) as e:
+        api.init(0)
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(api.PmapError):
+        api.Reads.from_list([b"ACGT"])
+
+
+def test_fraction_bits():
+    for e, bits in [(0.11, 0x3DC4A8BB), (0.001, 0x3EFC304B), (0.0001, 0x3EFF9DC6)]:
+        assert struct.unpack("<I", struct.pack("<f", api.fraction(e, 15)))[0] == bits
+
+
+def _ranks_by_python(si):
+    """Rank of every record's (prg, path) in (prg, prg::Path::operator<) order, independently in Python."""
+    keys = []
+    for j in range(len(si.rec_prg)):
+        a, b = int(si.path_off[j]), int(si.path_off[j + 1])
+        keys.append((int(si.rec_prg[j]), [(int(si.iv_start[q]), int(si.iv_len[q])) for q in range(a, b)]))
+    order = sorted(range(len(keys)), key=lambda j: keys[j])
+    rank = np.zeros(len(keys), np.uint32)
+    r = 0
+    for i, j in enumerate(order):
+        if i and keys[order[i - 1]] != keys[j]:
+            r += 1
+        rank[j] = r
+    return rank
+
+
+def test_index_create_path_ranks_and_accessors():
+    rng = np.random.default_rng(0)
+    loci = [synth.random_dna(int(rng.integers(60, 200)), rng) for _ in range(6)]
+    loci.append(loci[2].copy())
+    si = synth.build_index(loci, 3, 7, rng=rng, split_paths=0.5)
+    idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                           si.iv_start, si.iv_len, si.min_path_length)
+    info = idx.info()
+    assert info["n_keys"] == len(si.keys) and info["n_recs"] == len(si.rec_prg) and info["n_prg"] == len(loci)
+    assert info["table_slots"] >= 2 * info["n_keys"] and info["table_slots"] & (info["table_slots"] - 1) == 0
+    rec = idx.records()
+    np.testing.assert_array_equal(rec["prg"], si.rec_prg)
+    np.testing.assert_array_equal(rec["knode"], si.rec_knode)
+    np.testing.assert_array_equal(rec["strand"], si.rec_strand)
+    np.testing.assert_array_equal(rec["path_off"], si.path_off)
+    np.testing.assert_array_equal(rec["iv_start"], si.iv_start)
+    np.testing.assert_array_equal(rec["key"], np.repeat(si.keys, np.diff(si.rec_off).astype(np.int64)))
+    np.testing.assert_array_equal(rec["path_rank"], _ranks_by_python(si))
+    # the ranks order paths exactly as the reference build's prg::Path::operator<
+    r = O.ref()
+    if r is not None:
+        for _ in range(300):
+            a, b = (int(x) for x in rng.integers(0, len(si.rec_prg), 2))
+            if si.rec_prg[a] != si.rec_prg[b]:
+                continue
+            pa = [int(si.path_off[a]), int(si.path_off[a + 1])]
+            pb = [int(si.path_off[b]), int(si.path_off[b + 1])]
+            c = r.ref_path_cmp(si.iv_start[pa[0]:pa[1]].ctypes.data_as(O.u32p), si.iv_len[pa[0]:pa[1]].ctypes.data_as(O.u32p),
+                               pa[1] - pa[0], si.iv_start[pb[0]:pb[1]].ctypes.data_as(O.u32p),
+                               si.iv_len[pb[0]:pb[1]].ctypes.data_as(O.u32p), pb[1] - pb[0])
+            assert np.sign(int(rec["path_rank"][a]) - int(rec["path_rank"][b])) == c
+
+
+def test_index_create_rejects_bad_input():
+    ok = dict(k=3, keys=[5], rec_off=[0, 1], rec_prg=[0], rec_knode=[1], rec_strand=[1], path_off=[0, 1],
+              iv_start=[3], iv_len=[3], min_path_length=[4])
+    api.Index.create(**ok)
+    for bad, code in [(dict(ok, k=32), 1), (dict(ok, k=0), 1), (dict(ok, keys=[64]), 1),       # key >= 4^k
+                      (dict(ok, rec_prg=[1]), 1),                                                 # prg >= n_prg
+                      (dict(ok, iv_len=[4]), 1),                                                  # path length != k
+                      (dict(ok, rec_off=[0, 2], rec_prg=[0, 0], rec_knode=[1, 2], rec_strand=[1, 1],
+                            path_off=[0, 1, 2], iv_start=[3, 3], iv_len=[3, 3]), 5)]:            # duplicate record
+        with pytest.raises(api.PmapError) as e:
+            api.Index.create(**bad)
+        assert e.value.code == code
+    # same path on both strands is legal (MiniRecord::operator== includes the strand)
+    api.Index.create(**dict(ok, rec_off=[0, 2], rec_prg=[0, 0], rec_knode=[1, 2], rec_strand=[1, 0],
+                            path_off=[0, 1, 2], iv_start=[3, 3], iv_len=[3, 3]))
+
+
+def test_index_load_reference_fixture_files():
+    """test/test_cases/prg{1,2,3}.fa.idx (reference data files, w=1 k=3)."""
+    idx = api.Index.load(os.path.join(FIX, "prg1.fa.idx"), 3, [0, 3])
+    rec = idx.records()
+    assert list(rec["key"]) == [30, 30] and list(rec["prg"]) == [1, 1]
+    assert list(rec["knode"]) == [1, 2] and list(rec["strand"]) == [1, 0]
+    assert list(zip(rec["iv_start"], rec["iv_len"])) == [(0, 3), (1, 3)]
+    assert 30 == min(O.kmerhash("AGC", 3))
+    idx = api.Index.load(os.path.join(FIX, "prg3.fa.idx"), 3, [0, 0, 0, 5])
+    rec = idx.records()
+    assert idx.info()["n_keys"] == 2 and list(rec["key"]) == [6, 30, 30]
+    assert list(rec["path_off"]) == [0, 4, 8, 12]
+    assert list(zip(rec["iv_start"][:4], rec["iv_len"][:4])) == [(4, 1), (12, 1), (16, 0), (23, 1)]
+    assert rec["path_rank"][1] < rec["path_rank"][2] < rec["path_rank"][0]
+    with pytest.raises(api.PmapError) as e:
+        api.Index.load(os.path.join(FIX, "does_not_exist.idx"), 3, [0])
+    assert e.value.code == 3 and "Have you run pandora index?" in str(e.value)
+
+
+def test_index_text_round_trip(tmp_path):
+    """Index::save format (src/index.cpp:51-68) written by the test, parsed by the library."""
+    rng = np.random.default_rng(1)
+    si = synth.build_index([synth.random_dna(150, rng) for _ in range(5)], 4, 9, rng=rng, split_paths=0.4)
+    lines = [str(len(si.keys))]
+    for i, key in enumerate(si.keys):
+        recs = []
+        for j in range(int(si.rec_off[i]), int(si.rec_off[i + 1])):
+            a, b = int(si.path_off[j]), int(si.path_off[j + 1])
+            path = "%d{%s}" % (b - a, "".join("[%d, %d)" % (si.iv_start[q], si.iv_start[q] + si.iv_len[q])
+                                              for q in range(a, b)))
+            recs.append("(%d, %s, %d, %d)" % (si.rec_prg[j], path, si.rec_knode[j], si.rec_strand[j]))
+        lines.append("%d\t%d\t%s" % (key, len(recs), "\t".join(recs)))
+    p = tmp_path / "x.k9.w4.idx"
+    p.write_text("\n".join(lines) + "\n")
+    idx = api.Index.load(p, 9, si.min_path_length)
+    rec = idx.records()
+    np.testing.assert_array_equal(rec["prg"], si.rec_prg)
+    np.testing.assert_array_equal(rec["knode"], si.rec_knode)
+    np.testing.assert_array_equal(rec["strand"], si.rec_strand)
+    np.testing.assert_array_equal(rec["iv_start"], si.iv_start)
+    np.testing.assert_array_equal(rec["iv_len"], si.iv_len)
+
+
+def test_gfa_min_path_length(tmp_path):
+    cases = list(RC.BIGGER_INFER["graphs"].values()) + list(RC.SIMPLE_INFER["graphs"].values())
+    for i, (paths, edges) in enumerate(cases):
+        p = tmp_path / ("g%d.gfa" % i)
+        p.write_text(RC.gfa_text(paths, edges))
+        assert api.gfa_min_path_length(p) == RC.min_path_length(paths, edges)
+    # linear kmer graph: number of minimizer nodes + 1
+    paths = [[(0, 0)]] + [[(j, j + 5)] for j in range(0, 40, 3)] + [[(45, 45)]]
+    edges = [(i, i + 1) for i in range(len(paths) - 1)]
+    p = tmp_path / "lin.gfa"
+    p.write_text(RC.gfa_text(paths, edges))
+    assert api.gfa_min_path_length(p) == len(paths) - 1
+    with pytest.raises(api.PmapError):
+        api.gfa_min_path_length(tmp_path / "missing.gfa")
+
+
+def test_read_fastaq_reference_fixtures():
+    for name in ["reads.fa", "reads.fq", "reads.fa.gz", "reads.fq.gz", "read2.fa", "read2.fq", "read0.fa",
+                 "test.fastq", "oxa9_read.fasta", "loman_k12_merged_pass.mm2.sorted_1196-1216.fastq"]:
+        path = os.path.join(FIX, name)
+        raw = open(path, "rb").read()
+        if name.endswith(".gz"):
+            import gzip
+            raw = gzip.decompress(raw)
+        assert api.read_fastaq(path) == O.fastaq_iterate(raw), name
+    got = api.read_fastaq(os.path.join(FIX, "reads.fa.gz"))
+    assert got[:2] == [("read0", "to be ignored"), ("read1", "should copy the phrase *should*")]
+    assert len(api.read_fastaq(os.path.join(FIX, "loman_k12_merged_pass.mm2.sorted_1196-1216.fastq"))) >= 2
+    with pytest.raises(api.PmapError) as e:
+        api.read_fastaq(os.path.join(FIX, "nope.fa"))
+    assert e.value.code == 3
+
+
+def test_read_fastaq_quirks(tmp_path):
+    for i, buf in enumerate([b">a\nACGT\n\n\n", b">a\nACGT\nAC", b"@a\nACGT\n+\n@@@@\n@b\nGG\n+\n!!\n", b"",
+                             b">a\n>b\nAC\nGT\n>c\n", b"ACGT\n>x\nGG\n", b"\n\n>a\nAC\n"]):
+        p = tmp_path / ("q%d.fa" % i)
+        p.write_bytes(buf)
+        assert api.read_fastaq(p) == O.fastaq_iterate(buf), buf
+
+
+def test_filter_clusters_matches_oracle():
+    rng = np.random.default_rng(5)
+    for trial in range(5):
+        k, w = 7, 2
+        loci = [synth.random_dna(int(rng.integers(150, 400)), rng) for _ in range(6)]
+        loci += [loci[0][20:].copy(), synth.revcomp(loci[1])]
+        si = synth.build_index(loci, w, k, rng=rng, split_paths=0.3)
+        fi = O.FlatIndex(si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off, si.iv_start,
+                         si.iv_len)
+        genome = np.concatenate(loci + [synth.revcomp(x) for x in loci[:3]])
+        bases, off = synth.simulate_reads(genome, 30, rng, mean_len=600, e_rate=0.02)
+        res = O.oracle_map(fi, bases, off, np.arange(30, dtype=np.uint32), w, k, 15, 0.02, 2, 0xFFFFFFFF,
+                           si.min_path_length)
+        n = len(res["cl_size"])
+        assert n > 10 and 0 < res["cl_alive"].sum() < n
+        rank = _ranks_by_python(si)
+        perm = rng.permutation(n)
+        first_rec = res["hit_rec"][res["cl_begin"].astype(np.int64)]
+        cl = {"read": res["cl_read"][perm], "first_pos": res["cl_first_pos"][perm], "size": res["cl_size"][perm],
+              "prg": res["cl_prg"][perm], "first_rank": rank[first_rec][perm], "fwd": res["cl_fwd"][perm],
+              "last_pos": res["cl_last_pos"][perm]}
+        order, alive = api.filter_clusters(cl)
+        np.testing.assert_array_equal(perm[order.astype(np.int64)], np.arange(n))
+        np.testing.assert_array_equal(alive, res["cl_alive"])
+
+
+def test_shard_bounds():
+    off = np.array([0, 10, 10, 30, 35, 100, 101], np.uint64)
+    for world in (1, 2, 3, 4, 8):
+        b = sharding.shard_bounds(off, world)
+        assert len(b) == world and b[0][0] == 0 and b[-1][1] == 6
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+    bases = np.arange(101, dtype=np.uint8)
+    sb, so, first = sharding.shard(bases, off, 1, 2)
+    assert first == sharding.shard_bounds(off, 2)[1][0] and so[0] == 0 and len(sb) == int(so[-1])
+
+
+def _gloo_worker(rank, world, port, si_arrays, bases, off, prm, q):
+    """One rank of a 2-rank CPU rehearsal of the multi-GPU flow: shard -> map own shard (the oracle
+    stands in for the GPU kernels here) -> gather tables on rank 0 in read-id order."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    fi = O.FlatIndex(*si_arrays[:-1])
+    sb, so, first = sharding.shard(bases, off, rank, world)
+    ids = np.arange(first, first + len(so) - 1, dtype=np.uint32)
+    r = O.oracle_map(fi, sb, so, ids, *prm, si_arrays[-1])
+    alive = r["cl_alive"].astype(bool)
+    local = {k: r[k][alive] for k in ("cl_read", "cl_prg", "cl_fwd", "cl_size", "cl_first_pos", "cl_last_pos")}
+    merged = sharding.gather_tables(local, dst=0)
+    dist.barrier()
+    if rank == 0:
+        q.put(merged)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_gloo():
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(6)
+    loci = synth.make_loci(15, rng)
+    si = synth.build_index(loci, 14, 15)
+    genome = synth.make_genome(loci, rng)
+    bases, off = synth.simulate_reads(genome, 40, rng, mean_len=3000, e_rate=0.05)
+    arrays = (si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off, si.iv_start, si.iv_len,
+              si.min_path_length)
+    prm = (14, 15, 250, api.fraction(0.11, 15), 10, 0xFFFFFFFF)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + int(rng.integers(0, 2000))
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, arrays, bases, off, prm, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = O.oracle_map(O.FlatIndex(*arrays[:-1]), bases, off, np.arange(40, dtype=np.uint32), *prm, arrays[-1])
+    alive = one["cl_alive"].astype(bool)
+    assert alive.sum() > 5
+    for k in merged:
+        np.testing.assert_array_equal(merged[k], one[k][alive])
