@@ -24,8 +24,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 # kernels of each phase (names of pmap_kernel_name)
 PHASES = {
-    "sketch": ["sketch_flags", "sketch_scan", "sketch_emit"],
-    "probe": ["probe", "hit_scan", "scatter", "seg_bounds"],
+    "sketch": ["sketch"],          # fused mode: the index lookup runs inside this kernel
+    "probe": ["probe", "tile_scan", "scatter", "seg_bounds"],
     "sort": ["sort_rank"],
     "cluster": ["cluster_flags", "cluster_scan", "cluster_starts", "cluster_table", "kept_scan", "kept_gather"],
 }

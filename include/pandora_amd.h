@@ -126,7 +126,15 @@ typedef struct {
     uint32_t expected_kmers;    /* expected_number_kmers_in_short_read_sketch, src/utils.cpp:395,413-416 */
     uint32_t last_stage;        /* PMAP_STAGE_*; 0 = all */
     uint32_t profile;           /* 1: record per-stage HIP-event times; 2: also per kernel */
+    uint32_t flags;             /* PMAP_FLAG_* */
 } pmap_params_t;
+
+/* By default the index lookup runs inside the sketch kernel and only minimizers
+ * that have records are kept.  With this flag the sketch kernel keeps every
+ * minimizer (pmap_result_minimizers works) and the lookup runs as its own
+ * kernel; hits and clusters are the same either way.  last_stage =
+ * PMAP_STAGE_SKETCH implies it. */
+#define PMAP_FLAG_UNFUSED 1u
 
 /* 0.5 / exp(e_rate * k) as src/utils.cpp:394 evaluates it (float). */
 float pmap_fraction(float e_rate, uint32_t k);
@@ -161,7 +169,8 @@ int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out);
 int pmap_result_kernel_ms(const pmap_result_t *res, float *ms);
 const char *pmap_kernel_name(int i);
 
-/* Seq::sketch of every read, concatenated in (read, position) order. */
+/* Seq::sketch of every read, concatenated in (read, position) order.  Needs a
+ * result of a call with PMAP_FLAG_UNFUSED or last_stage = PMAP_STAGE_SKETCH. */
 int pmap_result_minimizers(const pmap_result_t *res, uint64_t *kmer, uint32_t *read_id, uint32_t *pos,
                            uint8_t *strand);
 /* MinimizerHits::hits in MinimizerHit::operator< order (src/minihit.cpp:44-66).

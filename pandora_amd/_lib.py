@@ -32,7 +32,7 @@ class IndexInfo(C.Structure):
 class Params(C.Structure):
     _fields_ = [("w", C.c_uint32), ("k", C.c_uint32), ("max_diff", C.c_int32), ("fraction", C.c_float),
                 ("min_cluster_size", C.c_uint32), ("expected_kmers", C.c_uint32), ("last_stage", C.c_uint32),
-                ("profile", C.c_uint32)]
+                ("profile", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class Counts(C.Structure):

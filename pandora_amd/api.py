@@ -229,10 +229,11 @@ class MapResult:
 
 
 def map_reads(index, reads, w, k, max_diff, fraction_required, min_cluster_size=10, expected_kmers=UINT32_MAX,
-              last_stage=0, profile=0, result=None):
+              last_stage=0, profile=0, result=None, unfused=False):
     """Seq::minimizer_sketch -> add_read_hits -> MinimizerHits::sort -> define_clusters on the GPU."""
     res = result if result is not None else MapResult()
-    prm = _lib.Params(w, k, max_diff, fraction_required, min_cluster_size, expected_kmers, last_stage, profile)
+    prm = _lib.Params(w, k, max_diff, fraction_required, min_cluster_size, expected_kmers, last_stage, profile,
+                      1 if unfused else 0)
     _check(_lib.load().pmap_map(index._h, reads._h, C.byref(prm), C.byref(res._h)))
     return res
 

@@ -25,8 +25,14 @@ struct PmapRec {
 
 static const uint64_t PMAP_EMPTY_KEY = ~0ULL;
 
-static inline uint32_t pmap_slot_of(uint64_t key, uint32_t log2cap) {
-    return (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> (64 - log2cap));
+// Home slot of a key.  Keys are hash64 outputs already, one 32-bit multiply spreads them enough.
+#ifdef __HIPCC__
+#define PMAP_HD __host__ __device__
+#else
+#define PMAP_HD
+#endif
+PMAP_HD static inline uint32_t pmap_slot_of(uint64_t key, uint32_t log2cap) {
+    return (((uint32_t) key ^ (uint32_t) (key >> 32)) * 2654435761u) >> (32 - log2cap);
 }
 
 struct pmap_index {

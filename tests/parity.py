@@ -1,5 +1,7 @@
 """Shared helper: run one batch through the GPU path and through the oracle and compare every
-stage bit for bit (minimizers, sorted hits, kept clusters, filter_clusters survivors)."""
+stage bit for bit (minimizers, sorted hits, kept clusters, filter_clusters survivors).  Both device
+modes are checked: the default one (index lookup fused into the sketch kernel) and the unfused one
+that keeps the complete minimizer list."""
 import numpy as np
 
 import oracle_lib as O
@@ -18,40 +20,13 @@ def oracle_index(si):
                        si.iv_len)
 
 
-def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size=10, expected_kmers=UINT32_MAX,
-                  first_read_id=0, gidx=None, check_minimizers=True):
-    """Asserts GPU == oracle for one batch; returns (gpu counts, oracle result dict)."""
-    offsets = np.ascontiguousarray(offsets, np.uint64)
-    n_reads = len(offsets) - 1
-    own = gidx is None
-    if own:
-        gidx = gpu_index(si)
-    rd = api.Reads(bases, offsets, first_read_id)
-    res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers)
-    cn = res.counts()
-    ids = np.arange(first_read_id, first_read_id + n_reads, dtype=np.uint32)
-    orc = O.oracle_map(oracle_index(si), bases, offsets, ids, w, k, max_diff, fraction, min_cluster_size,
-                       expected_kmers, si.min_path_length)
-    assert orc["n_dup_hits"] == 0
-
-    # minimizer set per read (Seq::sketch)
-    assert cn["n_minimizers"] == len(orc["mini_kmer"])
-    if check_minimizers:
-        gm = res.minimizers()
-        so = orc["sketch_off"]
-        oread = np.repeat(ids, np.diff(so).astype(np.int64))
-        np.testing.assert_array_equal(gm["read"], oread)
-        np.testing.assert_array_equal(gm["pos"], orc["mini_pos"])
-        np.testing.assert_array_equal(gm["kmer"], orc["mini_kmer"])
-        np.testing.assert_array_equal(gm["strand"], orc["mini_strand"])
-
+def _check_hits_and_clusters(res, cn, orc):
     # MinimizerHits in MinimizerHit::operator< order
     gh = res.hits(sorted=True)
     assert cn["n_hits"] == len(orc["hit_read"])
     for a, b in (("read", "hit_read"), ("prg", "hit_prg"), ("fwd", "hit_fwd"), ("pos", "hit_pos"),
                  ("rec", "hit_rec")):
         np.testing.assert_array_equal(gh[a], orc[b], err_msg=a)
-
     # clusters kept by define_clusters, then clusterComp order and filter_clusters
     assert cn["n_clusters_all"] == orc["n_all_clusters"]
     gc = res.clusters()
@@ -66,6 +41,41 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
     np.testing.assert_array_equal(gc["first_pos"][o], orc["cl_first_pos"])
     np.testing.assert_array_equal(gc["last_pos"][o], orc["cl_last_pos"])
     np.testing.assert_array_equal(alive, orc["cl_alive"])
+
+
+def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size=10, expected_kmers=UINT32_MAX,
+                  first_read_id=0, gidx=None):
+    """Asserts GPU == oracle for one batch; returns (gpu counts, oracle result dict)."""
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n_reads = len(offsets) - 1
+    own = gidx is None
+    if own:
+        gidx = gpu_index(si)
+    rd = api.Reads(bases, offsets, first_read_id)
+    ids = np.arange(first_read_id, first_read_id + n_reads, dtype=np.uint32)
+    orc = O.oracle_map(oracle_index(si), bases, offsets, ids, w, k, max_diff, fraction, min_cluster_size,
+                       expected_kmers, si.min_path_length)
+    assert orc["n_dup_hits"] == 0
+
+    # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
+    res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, unfused=True)
+    cn = res.counts()
+    assert cn["n_minimizers"] == len(orc["mini_kmer"])
+    gm = res.minimizers()
+    so = orc["sketch_off"]
+    oread = np.repeat(ids, np.diff(so).astype(np.int64))
+    np.testing.assert_array_equal(gm["read"], oread)
+    np.testing.assert_array_equal(gm["pos"], orc["mini_pos"])
+    np.testing.assert_array_equal(gm["kmer"], orc["mini_kmer"])
+    np.testing.assert_array_equal(gm["strand"], orc["mini_strand"])
+    _check_hits_and_clusters(res, cn, orc)
+    res.close()
+
+    # default (fused) mode
+    res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers)
+    cn = res.counts()
+    assert cn["n_minimizers"] == len(orc["mini_kmer"])
+    _check_hits_and_clusters(res, cn, orc)
     res.close()
     rd.close()
     if own:

@@ -32,7 +32,8 @@ def test_split_paths_and_first_read_id(gpu):
 
 
 @pytest.mark.parametrize("w,k", [(1, 15), (5, 15), (10, 11), (14, 15), (19, 19), (31, 31), (7, 16), (12, 21),
-                                 (1, 31), (14, 3), (3, 5)])
+                                 (1, 31), (14, 3), (3, 5), (2, 7), (4, 9), (5, 9), (6, 6), (8, 10), (17, 17),
+                                 (33, 12), (64, 15), (63, 31), (13, 15), (15, 15), (16, 15)])
 def test_wk_grid(gpu, w, k):
     si, bases, off = _small_world(10 + w + 100 * k, w, k, n_loci=12, n_reads=25, mean_len=1500, e_rate=0.03)
     compare_batch(si, bases, off, w, k, 100, api.fraction(0.05, k), min_cluster_size=3)
