@@ -122,7 +122,7 @@ struct pmap_result {
     // per tile
     DevBuf tile_nmini, tile_nent, tile_nhits, tile_hoff, bsum, scratch_total;
     // tile-slotted entries
-    DevBuf mkmer, e_read, e_ps, e_roff, e_cnt;
+    DevBuf mkmer, ents;
     // hits before / after sort
     DevBuf h_read, h_key, h_pos, h_rank, h_rec, hstart, hend;
     DevBuf s_read, s_key, s_pos, s_rank, s_rec;
@@ -137,8 +137,8 @@ struct pmap_result {
     hipEvent_t kev[2 * PMAP_N_KERNELS];
     bool events = false;
     std::vector<DevBuf *> all() {
-        return {&counters, &tile_nmini, &tile_nent, &tile_nhits, &tile_hoff, &bsum, &scratch_total, &mkmer, &e_read,
-                &e_ps, &e_roff, &e_cnt, &h_read, &h_key, &h_pos, &h_rank, &h_rec, &hstart, &hend, &s_read, &s_key,
+        return {&counters, &tile_nmini, &tile_nent, &tile_nhits, &tile_hoff, &bsum, &scratch_total, &mkmer, &ents,
+                &h_read, &h_key, &h_pos, &h_rank, &h_rec, &hstart, &hend, &s_read, &s_key,
                 &s_pos, &s_rank, &s_rec, &cflags, &coffs, &cstart, &c_size, &c_read, &c_key, &c_first, &c_last,
                 &c_rank, &kflags, &koffs, &kidx, &k_rows, &thr};
     }
@@ -338,16 +338,24 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
 #define SKETCH_ARGS                                                                                                   \
     rd->packed.as<uint32_t>(), rd->wread.as<uint32_t>(), rd->woff.as<uint32_t>(), rd->rlen.as<uint32_t>(),            \
         rd->rflag.as<uint32_t>(), rd->n_words, n_tiles, w, k, idx->d_slots, idx->log2cap, res->mkmer.as<uint64_t>(),           \
-        res->e_read.as<uint32_t>(), res->e_ps.as<uint32_t>(), res->e_roff.as<uint32_t>(), res->e_cnt.as<uint32_t>(),  \
-        res->tile_nmini.as<uint32_t>(), res->tile_nent.as<uint32_t>(), res->tile_nhits.as<uint32_t>()
-        if (k32 && fused)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sketch_wave_kernel<uint32_t, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, SKETCH_ARGS);
-        else if (k32)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sketch_wave_kernel<uint32_t, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, SKETCH_ARGS);
-        else if (fused)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sketch_wave_kernel<uint64_t, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, SKETCH_ARGS);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sketch_wave_kernel<uint64_t, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, SKETCH_ARGS);
+        res->ents.as<uint4>(), res->tile_nmini.as<uint32_t>(), res->tile_nent.as<uint32_t>(),                         \
+        res->tile_nhits.as<uint32_t>()
+#define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), dim3(256), 0,     \
+                       g_stream, SKETCH_ARGS)
+        // w = 14 (the default of pandora map) and w = 1 (dense sketches) have their own instantiations
+#define SKETCH_DISPATCH(HT, FUSED)                                                                                    \
+    do {                                                                                                              \
+        if (w == 14) SKETCH_LAUNCH(HT, FUSED, 14);                                                                    \
+        else if (w == 1) SKETCH_LAUNCH(HT, FUSED, 1);                                                                 \
+        else SKETCH_LAUNCH(HT, FUSED, 0);                                                                             \
+    } while (0)
+        if (k32 && fused) SKETCH_DISPATCH(uint32_t, true);
+        else if (k32) SKETCH_DISPATCH(uint32_t, false);
+        else if (fused) SKETCH_DISPATCH(uint64_t, true);
+        else SKETCH_DISPATCH(uint64_t, false);
+#undef SKETCH_DISPATCH
+#undef SKETCH_LAUNCH
 #undef SKETCH_ARGS
         kt.end(KT_SKETCH);
         HIP_TRY(hipGetLastError());
@@ -359,8 +367,8 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         if (!fused) {
             kt.begin(KT_PROBE);
             hipLaunchKernelGGL(probe_wave_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, res->mkmer.as<uint64_t>(),
-                               res->tile_nent.as<uint32_t>(), n_tiles, idx->d_slots, idx->log2cap, res->e_roff.as<uint32_t>(),
-                               res->e_cnt.as<uint32_t>(), res->tile_nhits.as<uint32_t>());
+                               res->tile_nent.as<uint32_t>(), n_tiles, idx->d_slots, idx->log2cap, res->ents.as<uint4>(),
+                               res->tile_nhits.as<uint32_t>());
             kt.end(KT_PROBE);
         }
         kt.begin(KT_TILE_SCAN);
@@ -371,9 +379,9 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
             return rc;
         kt.end(KT_TILE_SCAN);
         kt.begin(KT_SCATTER);
-        hipLaunchKernelGGL(scatter_wave_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, res->tile_nent.as<uint32_t>(),
-                           res->tile_hoff.as<uint32_t>(), n_tiles, res->e_read.as<uint32_t>(), res->e_ps.as<uint32_t>(),
-                           res->e_roff.as<uint32_t>(), res->e_cnt.as<uint32_t>(), idx->d_recs, res->hit_cap,
+        hipLaunchKernelGGL(scatter_group_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, g_stream,
+                           res->tile_nent.as<uint32_t>(), res->tile_hoff.as<uint32_t>(), n_tiles,
+                           res->ents.as<uint4>(), idx->d_recs, res->hit_cap,
                            res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
                            res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
         kt.end(KT_SCATTER);
@@ -513,8 +521,7 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
     const size_t tb = sizeof(uint32_t) * ((size_t) n_tiles + 1), sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS;
     if ((rc = res->counters.ensure(sizeof(Counters))) || (rc = res->tile_nmini.ensure(tb)) ||
         (rc = res->tile_nent.ensure(tb)) || (rc = res->tile_nhits.ensure(tb)) || (rc = res->tile_hoff.ensure(tb)) ||
-        (rc = res->e_read.ensure(sb)) || (rc = res->e_ps.ensure(sb)) || (rc = res->e_roff.ensure(sb)) ||
-        (rc = res->e_cnt.ensure(sb)) || (rc = res->hstart.ensure(sizeof(uint32_t) * (rd->n_reads + 1))) ||
+        (rc = res->ents.ensure(4 * sb)) || (rc = res->hstart.ensure(sizeof(uint32_t) * (rd->n_reads + 1))) ||
         (rc = res->hend.ensure(sizeof(uint32_t) * (rd->n_reads + 1))))
         return rc;
     if (!fused && (rc = res->mkmer.ensure(2 * sb))) return rc;
@@ -629,7 +636,7 @@ extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer,
         return done(rc);
     hipLaunchKernelGGL(compact_minimizers_kernel, dim3((res->n_tiles + 3) / 4), dim3(256), 0, g_stream,
                        res->tile_nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles, res->mkmer.as<uint64_t>(),
-                       res->e_read.as<uint32_t>(), res->e_ps.as<uint32_t>(), okm.as<uint64_t>(), ord.as<uint32_t>(),
+                       res->ents.as<uint4>(), okm.as<uint64_t>(), ord.as<uint32_t>(),
                        ops.as<uint32_t>());
     if (hipStreamSynchronize(g_stream) != hipSuccess) return done(pmap_fail(PMAP_EHIP, "minimizer gather failed"));
     if (kmer && hipMemcpy(kmer, okm.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)

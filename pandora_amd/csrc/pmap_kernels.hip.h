@@ -203,101 +203,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict_
 
 #include "pmap_sketch.hip.h"
 
-// exclusive scan of one value per lane over the wavefront; *total = wavefront sum
-__device__ __forceinline__ uint32_t wave_scan(uint32_t v, uint32_t *total) {
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(incl, d);
-        if (lane >= (uint32_t) d) incl += t;
-    }
-    *total = __shfl(incl, 63);
-    return incl - v;
-}
-
-// probe as its own kernel (unfused mode): one wavefront per sub-tile looks up the sub-tile's minimizers
-__global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restrict__ mkmer,
-                                                         const uint32_t *__restrict__ tile_nent, uint32_t n_tiles,
-                                                         const PmapSlot *__restrict__ slots, uint32_t log2cap,
-                                                         uint32_t *__restrict__ e_roff, uint32_t *__restrict__ e_cnt,
-                                                         uint32_t *__restrict__ tile_nhits) {
-    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_tiles) return;
-    const uint32_t n = tile_nent[g];
-    const uint64_t slot0 = (uint64_t) g * WAVE_POS;
-    uint32_t mine = 0;
-    for (uint32_t e = lane; e < n; e += 64) {
-        uint32_t cnt, off;
-        table_lookup(slots, log2cap, mkmer[slot0 + e], &cnt, &off);
-        e_roff[slot0 + e] = off;
-        e_cnt[slot0 + e] = cnt;
-        mine += cnt;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
-    if (lane == 0) tile_nhits[g] = mine;
-}
-
-// scatter: one wavefront per sub-tile writes the hits of the sub-tile's entries (MinimizerHit ctor,
-// src/minihit.cpp:14-22) at the sub-tile's offset; entries stay in (read, position) order
-__global__ __launch_bounds__(256) void scatter_wave_kernel(
-    const uint32_t *__restrict__ tile_nent, const uint32_t *__restrict__ tile_hoff, uint32_t n_tiles,
-    const uint32_t *__restrict__ e_read, const uint32_t *__restrict__ e_ps, const uint32_t *__restrict__ e_roff,
-    const uint32_t *__restrict__ e_cnt, const PmapRec *__restrict__ recs, uint32_t hit_cap,
-    uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key, uint32_t *__restrict__ h_pos,
-    uint32_t *__restrict__ h_rank, uint32_t *__restrict__ h_rec) {
-    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_tiles) return;
-    const uint32_t n = tile_nent[g];
-    if (n == 0) return;
-    const uint64_t slot0 = (uint64_t) g * WAVE_POS;
-    uint32_t run = tile_hoff[g];
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t e = base + lane;
-        uint32_t c = 0, ro = 0, r = 0, ps = 0;
-        if (e < n) {
-            c = e_cnt[slot0 + e];
-            if (c) { ro = e_roff[slot0 + e]; r = e_read[slot0 + e]; ps = e_ps[slot0 + e]; }
-        }
-        uint32_t tot;
-        const uint32_t ho = run + wave_scan(c, &tot);
-        const uint32_t pos = ps & 0x7FFFFFFFu, strand = ps >> 31;
-        for (uint32_t q = 0; q < c; ++q) {
-            const uint32_t d = ho + q;
-            if (d >= hit_cap) break;
-            const uint4 rec = *(const uint4 *) (recs + ro + q);   // prg, knode<<1|strand, rank, orig
-            const uint32_t fwd = (strand == (rec.y & 1u));
-            h_read[d] = r;
-            h_key[d] = rec.x << 1 | (fwd ? 0u : 1u);              // forward hits sort first (src/minihit.cpp:54-55)
-            h_pos[d] = pos;
-            h_rank[d] = rec.z;
-            h_rec[d] = rec.w;
-        }
-        run += tot;
-    }
-}
-
-// gathers the slotted minimizers into one contiguous list (only when a caller asks for them)
-__global__ __launch_bounds__(256) void compact_minimizers_kernel(const uint32_t *__restrict__ tile_nmini,
-                                                                 const uint32_t *__restrict__ tile_moff,
-                                                                 uint32_t n_tiles,
-                                                                 const uint64_t *__restrict__ mkmer,
-                                                                 const uint32_t *__restrict__ e_read,
-                                                                 const uint32_t *__restrict__ e_ps,
-                                                                 uint64_t *__restrict__ o_kmer,
-                                                                 uint32_t *__restrict__ o_read,
-                                                                 uint32_t *__restrict__ o_ps) {
-    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_tiles) return;
-    const uint32_t n = tile_nmini[g], o = tile_moff[g];
-    const uint64_t slot0 = (uint64_t) g * WAVE_POS;
-    for (uint32_t e = lane; e < n; e += 64) {
-        o_kmer[o + e] = mkmer[slot0 + e];
-        o_read[o + e] = e_read[slot0 + e];
-        o_ps[o + e] = e_ps[slot0 + e];
-    }
-}
+#include "pmap_emit.hip.h"
 
 __device__ __forceinline__ uint32_t clamp_count(const unsigned long long *p, uint32_t cap) {
     const unsigned long long v = *p;

@@ -139,18 +139,19 @@ __device__ __forceinline__ Quad<HT> window_max_fwd(const HT *L, int Q, int f, in
     return out;
 }
 
-// FUSED = false: every minimizer of the wavefront goes to its slots of (mkmer, e_read, e_ps).
+// FUSED = false: every minimizer of the wavefront goes to its slots of (mkmer, ents).
 // FUSED = true : every minimizer is looked up in the index at once; only those with records go
-//                to the slots of (e_read, e_ps, e_roff, e_cnt); the wavefront's hit count is kept.
+//                to the slots of ents; the wavefront's hit count is kept.
+// WC > 0 fixes w at compile time (window shapes unroll); WC = 0 takes w from the argument.
 // Wavefront g owns output positions [g * 4 * out_q, (g + 1) * 4 * out_q), out_q = 64 - 2 * edge.
-template <typename HT, bool FUSED>
+template <typename HT, bool FUSED, int WC>
 __global__ __launch_bounds__(256) void sketch_wave_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ wread, const uint32_t *__restrict__ woff,
     const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ rflag, uint32_t n_words, uint32_t n_tiles,
-    uint32_t w, uint32_t k, const PmapSlot *__restrict__ slots, uint32_t log2cap, uint64_t *__restrict__ mkmer,
-    uint32_t *__restrict__ e_read, uint32_t *__restrict__ e_ps, uint32_t *__restrict__ e_roff,
-    uint32_t *__restrict__ e_cnt, uint32_t *__restrict__ tile_nmini, uint32_t *__restrict__ tile_nent,
+    uint32_t w_arg, uint32_t k, const PmapSlot *__restrict__ slots, uint32_t log2cap, uint64_t *__restrict__ mkmer,
+    uint4 *__restrict__ ents, uint32_t *__restrict__ tile_nmini, uint32_t *__restrict__ tile_nent,
     uint32_t *__restrict__ tile_nhits) {
+    const uint32_t w = WC ? (uint32_t) WC : w_arg;
     __shared__ uint32_t sW[4][SK_NW], sStart[4][SK_NW], sLen[4][SK_NW], sRead[4][SK_NW];
     __shared__ __align__(16) HT sH[4][WAVE_POS];
     __shared__ __align__(16) uint32_t sJ[4][WAVE_POS];
@@ -302,8 +303,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     if (!FUSED) {
         for (uint32_t e = lane; e < n; e += 64) {
             mkmer[slot0 + e] = (uint64_t) c_h[e];
-            e_read[slot0 + e] = c_rd[e];
-            e_ps[slot0 + e] = c_ps[e];
+            ents[slot0 + e] = make_uint4(c_rd[e], c_ps[e], 0, 0);
         }
         if (lane == 0) {
             tile_nmini[g] = n;
@@ -319,10 +319,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
             if (cnt) {
                 const uint64_t s = slot0 + nent +
                                    __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
-                e_read[s] = c_rd[e];
-                e_ps[s] = c_ps[e];
-                e_roff[s] = off;
-                e_cnt[s] = cnt;
+                ents[s] = make_uint4(c_rd[e], c_ps[e], off, cnt);
             }
             nent += __popcll(b);
             hits += cnt;
