@@ -125,7 +125,7 @@ typedef struct {
     uint32_t min_cluster_size;
     uint32_t expected_kmers;    /* expected_number_kmers_in_short_read_sketch, src/utils.cpp:395,413-416 */
     uint32_t last_stage;        /* PMAP_STAGE_*; 0 = all */
-    uint32_t profile;           /* 1: record per-stage HIP-event times; 2: also per kernel */
+    uint32_t profile;           /* 1: HIP-event time of every kernel; 2: of the sketch kernel only (cheapest) */
     uint32_t flags;             /* PMAP_FLAG_* */
 } pmap_params_t;
 
@@ -156,14 +156,17 @@ typedef struct {
     uint64_t n_hits;
     uint64_t n_clusters_all;    /* before the size threshold */
     uint64_t n_clusters;        /* kept by define_clusters */
-    /* HIP-event times of the last pmap_map with profile=1, milliseconds:
-     * 0 sketch, 1 probe (count+scan+scatter), 2 sort, 3 cluster, 4 total */
+    /* HIP-event times of the last pmap_map with profile=1, milliseconds (sums of
+     * the kernels of each phase): 0 sketch, 1 probe (scan+scatter), 2 sort,
+     * 3 cluster, 4 first kernel start to last kernel stop */
     float ms[PMAP_N_TIMERS];
 } pmap_counts_t;
 int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out);
 
 /* Per-kernel HIP-event times (milliseconds, on the library's stream) of the
- * last pmap_map call made with profile=2.  ms has PMAP_N_KERNELS entries;
+ * last pmap_map call made with profile != 0 (the events ride on the kernel
+ * dispatches; each timed kernel costs a few microseconds of dispatch gap).
+ * ms has PMAP_N_KERNELS entries, 0 for kernels that were not timed;
  * pmap_kernel_name(i) names entry i. */
 #define PMAP_N_KERNELS 16
 int pmap_result_kernel_ms(const pmap_result_t *res, float *ms);

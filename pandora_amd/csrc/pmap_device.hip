@@ -18,6 +18,7 @@
 //
 // All kernels are integer / byte work bounded by HBM bandwidth or VALU rate; none uses MFMA.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -133,7 +134,6 @@ struct pmap_result {
     const pmap_index *thr_idx = nullptr;
     float thr_fraction = 0;
     uint32_t thr_min = 0, thr_exp = 0;
-    hipEvent_t ev[8];
     hipEvent_t kev[2 * PMAP_N_KERNELS];
     bool events = false;
     std::vector<DevBuf *> all() {
@@ -284,21 +284,44 @@ extern "C" void pmap_reads_destroy(pmap_reads_t *rd) {
 // ---------------------------------------------------------------------------
 // map
 
+// Per-kernel timing: the start / stop events ride on the kernel dispatches themselves
+// (hipExtLaunchKernelGGL), so timing does not put extra packets between the kernels.
 struct KTimer {
     pmap_result *res;
     bool on;
+    uint32_t mask;           // kernels (bit per KT_*) that get events
     uint32_t recorded = 0;
-    void begin(int k) { if (on) (void) hipEventRecord(res->kev[2 * k], g_stream); }
+    int cur = -1;
+    bool first = false;
+    void begin(int k) { if (on && (mask >> k & 1u)) { cur = k; first = true; } }
     void end(int k) {
-        if (on) {
-            (void) hipEventRecord(res->kev[2 * k + 1], g_stream);
-            recorded |= 1u << k;
+        if (on && cur == k) {
+            if (!first) recorded |= 1u << k;   // at least one kernel was launched in the group
+            cur = -1;
         }
     }
+    // events for the next launch: the group's first launch carries the start event, every launch the stop event
+    void events(hipEvent_t *s, hipEvent_t *e);
 };
+static KTimer *g_kt = nullptr;
+
+#define KLAUNCH(kernel, grid, ...)                                                                        \
+    do {                                                                                                  \
+        hipEvent_t s_ = nullptr, e_ = nullptr;                                                            \
+        if (g_kt) g_kt->events(&s_, &e_);                                                                 \
+        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, g_stream, s_, e_, 0, __VA_ARGS__); \
+        else kernel<<<grid, dim3(256), 0, g_stream>>>(__VA_ARGS__);                                       \
+    } while (0)
 
 // exclusive scan (of values or popcounts) of n uint32 into out; the total stays on the device.
 // out may be null (total only).
+void KTimer::events(hipEvent_t *s, hipEvent_t *e) {
+    *s = *e = nullptr;
+    if (!on || cur < 0) return;
+    if (first) { *s = res->kev[2 * cur]; first = false; }
+    *e = res->kev[2 * cur + 1];
+}
+
 template <bool POPC>
 static int device_scan(pmap_result *res, const uint32_t *in, uint32_t *out, uint64_t n, unsigned long long *d_total) {
     if (n == 0) {
@@ -308,11 +331,11 @@ static int device_scan(pmap_result *res, const uint32_t *in, uint32_t *out, uint
     const uint32_t nblk = (uint32_t) ((n + SCAN_TILE - 1) / SCAN_TILE);
     int rc;
     if ((rc = res->bsum.ensure(sizeof(uint32_t) * nblk))) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_reduce_kernel<POPC>), dim3(nblk), dim3(256), 0, g_stream, in, n,
+    KLAUNCH(HIP_KERNEL_NAME(scan_reduce_kernel<POPC>), dim3(nblk), in, n,
                        res->bsum.as<uint32_t>());
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, g_stream, res->bsum.as<uint32_t>(), nblk, d_total);
+    KLAUNCH(scan_spine_kernel, dim3(1), res->bsum.as<uint32_t>(), nblk, d_total);
     if (out)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_apply_kernel<POPC>), dim3(nblk), dim3(256), 0, g_stream, in, n,
+        KLAUNCH(HIP_KERNEL_NAME(scan_apply_kernel<POPC>), dim3(nblk), in, n,
                            res->bsum.as<uint32_t>(), out);
     HIP_TRY(hipGetLastError());
     return PMAP_OK;
@@ -326,11 +349,10 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
     int rc;
     const uint32_t k = prm->k, w = prm->w;
     const bool k32 = k <= 15;
-    const bool prof = prm->profile != 0;
     const uint32_t n_tiles = res->n_tiles;
     Counters *dc = res->counters.as<Counters>();
     HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), g_stream));
-    if (prof) HIP_TRY(hipEventRecord(res->ev[0], g_stream));
+    g_kt = &kt;
 
     // ---- sketch (+ probe when fused)
     if (n_tiles) {
@@ -341,8 +363,7 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         res->ents.as<uint4>(), res->tile_nmini.as<uint32_t>(), res->tile_nent.as<uint32_t>(),                         \
         res->tile_nhits.as<uint32_t>()
 #define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), dim3(256), 0,     \
-                       g_stream, SKETCH_ARGS)
+    KLAUNCH(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
         // w = 14 (the default of pandora map) and w = 1 (dense sketches) have their own instantiations
 #define SKETCH_DISPATCH(HT, FUSED)                                                                                    \
     do {                                                                                                              \
@@ -360,13 +381,12 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         kt.end(KT_SKETCH);
         HIP_TRY(hipGetLastError());
     }
-    if (prof) HIP_TRY(hipEventRecord(res->ev[1], g_stream));
 
     // ---- probe (unfused) + hit emission
     if (last >= PMAP_STAGE_HITS && n_tiles) {
         if (!fused) {
             kt.begin(KT_PROBE);
-            hipLaunchKernelGGL(probe_wave_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, g_stream, res->mkmer.as<uint64_t>(),
+            KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(),
                                res->tile_nent.as<uint32_t>(), n_tiles, idx->d_slots, idx->log2cap, res->ents.as<uint4>(),
                                res->tile_nhits.as<uint32_t>());
             kt.end(KT_PROBE);
@@ -379,14 +399,14 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
             return rc;
         kt.end(KT_TILE_SCAN);
         kt.begin(KT_SCATTER);
-        hipLaunchKernelGGL(scatter_group_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, g_stream,
+        KLAUNCH(scatter_group_kernel, dim3((n_tiles + 255) / 256),
                            res->tile_nent.as<uint32_t>(), res->tile_hoff.as<uint32_t>(), n_tiles,
                            res->ents.as<uint4>(), idx->d_recs, res->hit_cap,
                            res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
                            res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
         kt.end(KT_SCATTER);
         kt.begin(KT_SEG_BOUNDS);
-        hipLaunchKernelGGL(seg_bounds_kernel, dim3(res->hit_cap / 256), dim3(256), 0, g_stream,
+        KLAUNCH(seg_bounds_kernel, dim3(res->hit_cap / 256),
                            res->h_read.as<uint32_t>(), &dc->n_hits, res->hit_cap, res->hstart.as<uint32_t>(),
                            res->hend.as<uint32_t>());
         kt.end(KT_SEG_BOUNDS);
@@ -394,12 +414,11 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
     } else if (n_tiles) {
         if ((rc = device_scan<false>(res, res->tile_nmini.as<uint32_t>(), nullptr, n_tiles, &dc->n_mini))) return rc;
     }
-    if (prof) HIP_TRY(hipEventRecord(res->ev[2], g_stream));
 
     // ---- sort
     if (last >= PMAP_STAGE_SORT && n_tiles) {
         kt.begin(KT_SORT);
-        hipLaunchKernelGGL(sort_rank_kernel, dim3(res->hit_cap / 256), dim3(256), 0, g_stream, &dc->n_hits,
+        KLAUNCH(sort_rank_kernel, dim3(res->hit_cap / 256), &dc->n_hits,
                            res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(),
                            res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(),
                            res->hstart.as<uint32_t>(), res->hend.as<uint32_t>(), res->s_read.as<uint32_t>(),
@@ -408,13 +427,12 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         kt.end(KT_SORT);
         HIP_TRY(hipGetLastError());
     }
-    if (prof) HIP_TRY(hipEventRecord(res->ev[3], g_stream));
 
     // ---- cluster
     if (last >= PMAP_STAGE_CLUSTER && n_tiles) {
         const uint32_t n_cfw = res->hit_cap / 32, n_kfw = res->cl_cap / 32;
         kt.begin(KT_CLUSTER_FLAGS);
-        hipLaunchKernelGGL(cluster_flags_kernel, dim3(res->hit_cap / 256), dim3(256), 0, g_stream, &dc->n_hits,
+        KLAUNCH(cluster_flags_kernel, dim3(res->hit_cap / 256), &dc->n_hits,
                            res->hit_cap, res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
                            res->s_pos.as<uint32_t>(), (int) prm->max_diff, res->cflags.as<unsigned long long>());
         kt.end(KT_CLUSTER_FLAGS);
@@ -423,12 +441,12 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
             return rc;
         kt.end(KT_CLUSTER_SCAN);
         kt.begin(KT_CLUSTER_STARTS);
-        hipLaunchKernelGGL(bit_positions_kernel, dim3((n_cfw + 255) / 256), dim3(256), 0, g_stream,
+        KLAUNCH(bit_positions_kernel, dim3((n_cfw + 255) / 256),
                            res->cflags.as<uint32_t>(), res->coffs.as<uint32_t>(), n_cfw, res->cl_cap,
                            res->cstart.as<uint32_t>());
         kt.end(KT_CLUSTER_STARTS);
         kt.begin(KT_CLUSTER_TABLE);
-        hipLaunchKernelGGL(cluster_table_kernel, dim3(res->cl_cap / 256), dim3(256), 0, g_stream, &dc->n_cl,
+        KLAUNCH(cluster_table_kernel, dim3(res->cl_cap / 256), &dc->n_cl,
                            res->cl_cap, &dc->n_hits, res->hit_cap, res->cstart.as<uint32_t>(),
                            res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(),
                            res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), res->c_size.as<uint32_t>(),
@@ -441,10 +459,10 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
             return rc;
         kt.end(KT_KEPT_SCAN);
         kt.begin(KT_KEPT_GATHER);
-        hipLaunchKernelGGL(bit_positions_kernel, dim3((n_kfw + 255) / 256), dim3(256), 0, g_stream,
+        KLAUNCH(bit_positions_kernel, dim3((n_kfw + 255) / 256),
                            res->kflags.as<uint32_t>(), res->koffs.as<uint32_t>(), n_kfw, res->cl_cap,
                            res->kidx.as<uint32_t>());
-        hipLaunchKernelGGL(cluster_gather_kernel, dim3(res->cl_cap / 256), dim3(256), 0, g_stream, &dc->n_kept,
+        KLAUNCH(cluster_gather_kernel, dim3(res->cl_cap / 256), &dc->n_kept,
                            res->cl_cap, res->kidx.as<uint32_t>(), res->cstart.as<uint32_t>(),
                            res->c_size.as<uint32_t>(), res->c_read.as<uint32_t>(), res->c_key.as<uint32_t>(),
                            res->c_first.as<uint32_t>(), res->c_last.as<uint32_t>(), res->c_rank.as<uint32_t>(),
@@ -452,7 +470,7 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         kt.end(KT_KEPT_GATHER);
         HIP_TRY(hipGetLastError());
     }
-    if (prof) HIP_TRY(hipEventRecord(res->ev[4], g_stream));
+    g_kt = nullptr;
     HIP_TRY(hipMemcpyAsync(hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     return PMAP_OK;
@@ -497,7 +515,6 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         res = new pmap_result();
         memset(&res->counts, 0, sizeof(res->counts));
         memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
-        for (auto &e : res->ev) HIP_TRY(hipEventCreate(&e));
         for (auto &e : res->kev) HIP_TRY(hipEventCreate(&e));
         res->events = true;
         *result = res;
@@ -549,7 +566,8 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         return rc;
 
     Counters hc;
-    KTimer kt{res, prm->profile >= 2};
+    KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
+    memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
     for (int attempt = 0;; ++attempt) {
         kt.recorded = 0;
         memset(&hc, 0, sizeof(hc));
@@ -574,16 +592,24 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
     cn.n_clusters_all = last >= PMAP_STAGE_CLUSTER ? hc.n_cl : 0;
     cn.n_clusters = last >= PMAP_STAGE_CLUSTER ? hc.n_kept : 0;
     res->have_minimizers = !fused;
-    if (prm->profile) {
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&cn.ms[i], res->ev[i], res->ev[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&cn.ms[4], res->ev[0], res->ev[4]));
-    }
     if (kt.on) {
         for (int i = 0; i < KT_COUNT; ++i) {
             float ms = 0;
             if ((kt.recorded >> i & 1u) && hipEventElapsedTime(&ms, res->kev[2 * i], res->kev[2 * i + 1]) == hipSuccess)
                 res->kernel_ms[i] = ms;
         }
+        // stage times = sums of their kernels; ms[4] = first kernel start to last kernel stop
+        const float *km = res->kernel_ms;
+        cn.ms[0] = km[KT_SKETCH];
+        cn.ms[1] = km[KT_PROBE] + km[KT_TILE_SCAN] + km[KT_SCATTER] + km[KT_SEG_BOUNDS];
+        cn.ms[2] = km[KT_SORT];
+        cn.ms[3] = km[KT_CLUSTER_FLAGS] + km[KT_CLUSTER_SCAN] + km[KT_CLUSTER_STARTS] + km[KT_CLUSTER_TABLE] +
+                   km[KT_KEPT_SCAN] + km[KT_KEPT_GATHER];
+        int lastk = -1;
+        for (int i = 0; i < KT_COUNT; ++i)
+            if (kt.recorded >> i & 1u) lastk = i;
+        if ((kt.recorded & 1u) && lastk >= 0)
+            (void) hipEventElapsedTime(&cn.ms[4], res->kev[0], res->kev[2 * lastk + 1]);
     }
     return PMAP_OK;
 }
@@ -705,7 +731,6 @@ extern "C" void pmap_result_destroy(pmap_result_t *res) {
     if (!res) return;
     for (DevBuf *b : res->all()) b->release();
     if (res->events) {
-        for (auto &e : res->ev) (void) hipEventDestroy(e);
         for (auto &e : res->kev) (void) hipEventDestroy(e);
     }
     delete res;

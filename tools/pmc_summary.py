@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Summaries of rocprofv3 --pmc passes over bench.py.
+
+    python tools/pmc_summary.py counters <counter_collection.csv>...
+        per-kernel averages of every counter in the files
+
+    python tools/pmc_summary.py traffic <workload> <fetch.csv> <write.csv> [out.json]
+        HBM-side bytes per launch of each phase of the path: FETCH_SIZE and WRITE_SIZE are reported in
+        KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled.
+        The result is merged into out.json (default profiles/pmc_traffic.json), which bench.py reads
+        for roofline.traffic.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+PHASE_OF = [("sketch_wave", "sketch"), ("probe_wave", "probe"), ("scan_", None), ("scatter_group", "probe"),
+            ("seg_bounds", "probe"), ("sort_rank", "sort"), ("cluster_flags", "cluster"), ("bit_positions", "cluster"),
+            ("cluster_table", "cluster"), ("cluster_gather", "cluster")]
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def counters(files):
+    for f in files:
+        for k, d in per_kernel(f).items():
+            print(k[:60], {c: round(sum(v) / len(v)) for c, v in d.items()})
+
+
+def phase_sums(path, counter):
+    """total of `counter` per phase and the number of sketch launches (= steps profiled)"""
+    tot = collections.defaultdict(float)
+    steps = 0
+    for k, d in per_kernel(path).items():
+        vals = d.get(counter)
+        if not vals:
+            continue
+        ph = None
+        for pat, p in PHASE_OF:
+            if pat in k:
+                ph = p if p else "scans"
+                break
+        if ph is None:
+            continue
+        tot[ph] += sum(vals)
+        if ph == "sketch":
+            steps += len(vals)
+    return tot, max(steps, 1)
+
+
+def traffic(workload, fetch_csv, write_csv, out):
+    f, sf = phase_sums(fetch_csv, "FETCH_SIZE")
+    w, sw = phase_sums(write_csv, "WRITE_SIZE")
+    res = {}
+    for ph in sorted(set(f) | set(w)):
+        rd = 2.0 * 1024.0 * f.get(ph, 0.0) / sf
+        wr = 1024.0 * w.get(ph, 0.0) / sw
+        res[ph] = rd + wr
+        res[ph + "_read"] = rd
+        res[ph + "_write"] = wr
+    cur = {}
+    if os.path.exists(out):
+        cur = json.load(open(out))
+    cur[workload] = res
+    cur["_note"] = ("bytes per launch of each phase; reads = 2 x FETCH_SIZE KiB (gfx950 tallies 128-byte requests "
+                    "as 64 bytes), writes = WRITE_SIZE KiB; separate --pmc passes; 'scans' (tile and cluster scans) "
+                    "are listed apart from the phases they belong to")
+    json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2:])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4],
+                sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(__file__), "..", "profiles",
+                                                                   "pmc_traffic.json"))
