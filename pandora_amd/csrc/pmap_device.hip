@@ -10,9 +10,9 @@
 //   sort     MinimizerHits::sort (src/minihits.cpp:42-53, order src/minihit.cpp:44-66)
 //   cluster  define_clusters (src/utils.cpp:189-249): cut flags, prefix sum, size threshold
 //
-// The batch is cut into tiles of 1024 k-mer start positions; sketch, probe and hit emission
-// work tile by tile and keep per-tile counts, so the only device-wide prefix sums run over
-// tiles.  Nothing on the path waits for the host: buffer capacities are carried over from the
+// The batch is cut into tiles of up to 512 k-mer start positions, one wavefront each; sketch,
+// probe and hit emission work tile by tile and keep per-tile counts, so the only device-wide
+// prefix sum runs over groups of 64 tiles.  Nothing on the path waits for the host: buffer capacities are carried over from the
 // previous call, every kernel guards its writes by capacity, and the counters are read back
 // once at the end (a too-small buffer is grown and the batch is mapped again).
 //
@@ -98,9 +98,11 @@ struct pmap_reads {
     uint64_t n_bases = 0;
     uint32_t n_words = 0;      // packed words, each read padded to a multiple of 16 bases
     uint32_t n_tiles = 0;
-    DevBuf ascii, boff, woff, rlen, rflag, packed, wread;
+    DevBuf ascii, boff, woff, rlen, rflag;
+    DevBuf words;    // uint2 per packed word: {16 bases, read index}
+    DevBuf rmeta;    // uint2 per read: {first position in the padded stream, length or 0 if not sketchable}
     uint64_t device_bytes() const {
-        return ascii.cap + boff.cap + woff.cap + rlen.cap + rflag.cap + packed.cap + wread.cap;
+        return ascii.cap + boff.cap + woff.cap + rlen.cap + rflag.cap + words.cap + rmeta.cap;
     }
 };
 
@@ -121,7 +123,7 @@ struct pmap_result {
     uint32_t hit_cap = 0, cl_cap = 0;
     DevBuf counters;
     // per tile
-    DevBuf tile_nmini, tile_nent, tile_nhits, tile_hoff, bsum, scratch_total;
+    DevBuf tile_cnt, group_sum, group_hoff, bsum, scratch_total;
     // tile-slotted entries
     DevBuf mkmer, ents;
     // hits before / after sort
@@ -137,7 +139,7 @@ struct pmap_result {
     hipEvent_t kev[2 * PMAP_N_KERNELS];
     bool events = false;
     std::vector<DevBuf *> all() {
-        return {&counters, &tile_nmini, &tile_nent, &tile_nhits, &tile_hoff, &bsum, &scratch_total, &mkmer, &ents,
+        return {&counters, &tile_cnt, &group_sum, &group_hoff, &bsum, &scratch_total, &mkmer, &ents,
                 &h_read, &h_key, &h_pos, &h_rank, &h_rec, &hstart, &hend, &s_read, &s_key,
                 &s_pos, &s_rank, &s_rec, &cflags, &coffs, &cstart, &c_size, &c_read, &c_key, &c_first, &c_last,
                 &c_rank, &kflags, &koffs, &kidx, &k_rows, &thr};
@@ -157,7 +159,12 @@ int pmap_index_upload(pmap_index *idx) {
     HIP_TRY(hipMemcpy(idx->d_slots, idx->slots.data(), sb, hipMemcpyHostToDevice));
     if (!idx->recs.empty())
         HIP_TRY(hipMemcpy(idx->d_recs, idx->recs.data(), idx->recs.size() * sizeof(PmapRec), hipMemcpyHostToDevice));
-    idx->device_bytes = sb + rb;
+    const size_t fb = idx->filter.size() * sizeof(uint32_t);
+    if (fb) {
+        HIP_TRY(hipMalloc((void **) &idx->d_filter, fb));
+        HIP_TRY(hipMemcpy(idx->d_filter, idx->filter.data(), fb, hipMemcpyHostToDevice));
+    }
+    idx->device_bytes = sb + rb + fb;
     return PMAP_OK;
 }
 
@@ -170,6 +177,8 @@ void pmap_index_release_device(pmap_index *idx) {
     if (idx->d_slots) (void) hipFree(idx->d_slots);
     if (idx->d_recs) (void) hipFree(idx->d_recs);
     if (idx->d_thr) (void) hipFree(idx->d_thr);
+    if (idx->d_filter) (void) hipFree(idx->d_filter);
+    idx->d_filter = nullptr;
     idx->d_slots = nullptr;
     idx->d_recs = nullptr;
     idx->d_thr = nullptr;
@@ -183,8 +192,14 @@ static int launch_encode(pmap_reads *rd) {
     if (rd->n_words) {
         hipLaunchKernelGGL(encode_kernel, dim3((rd->n_words + 255) / 256), dim3(256), 0, g_stream,
                            rd->ascii.as<uint32_t>(), rd->boff.as<uint64_t>(), rd->woff.as<uint32_t>(),
-                           rd->rlen.as<uint32_t>(), rd->n_reads, rd->n_words, rd->packed.as<uint32_t>(),
-                           rd->wread.as<uint32_t>(), rd->rflag.as<uint32_t>());
+                           rd->rlen.as<uint32_t>(), rd->n_reads, rd->n_words, rd->words.as<uint2>(),
+                           rd->rflag.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    if (rd->n_reads) {
+        hipLaunchKernelGGL(read_meta_kernel, dim3((rd->n_reads + 255) / 256), dim3(256), 0, g_stream,
+                           rd->woff.as<uint32_t>(), rd->rlen.as<uint32_t>(), rd->rflag.as<uint32_t>(), rd->n_reads,
+                           rd->rmeta.as<uint2>());
         HIP_TRY(hipGetLastError());
     }
     return PMAP_OK;
@@ -233,13 +248,13 @@ extern "C" int pmap_reads_create(const char *bases, const uint64_t *offsets, uin
         (rc = rd->woff.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->rlen.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->rflag.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
-        (rc = rd->packed.ensure(sizeof(uint32_t) * word_slots)) ||
-        (rc = rd->wread.ensure(sizeof(uint32_t) * word_slots)))
+        (rc = rd->words.ensure(sizeof(uint2) * word_slots)) ||
+        (rc = rd->rmeta.ensure(sizeof(uint2) * (n_reads + 1))))
         return fail(rc);
     hipError_t e;
     e = hipMemsetAsync((char *) rd->ascii.p + ((n_bases) & ~3ull), 0, ascii_bytes - (n_bases & ~3ull), g_stream);
-    if (e == hipSuccess) e = hipMemsetAsync(rd->packed.p, 0, sizeof(uint32_t) * word_slots, g_stream);
-    if (e == hipSuccess) e = hipMemsetAsync(rd->wread.p, 0, sizeof(uint32_t) * word_slots, g_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(rd->words.p, 0, sizeof(uint2) * word_slots, g_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(rd->rmeta.p, 0, sizeof(uint2) * (n_reads + 1), g_stream);
     if (e == hipSuccess && n_bases) e = hipMemcpyAsync(rd->ascii.p, bases + base0, n_bases, hipMemcpyHostToDevice, g_stream);
     if (e == hipSuccess) e = hipMemcpyAsync(rd->boff.p, boff.data(), sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice, g_stream);
     if (e == hipSuccess) e = hipMemcpyAsync(rd->woff.p, woff.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_stream);
@@ -277,7 +292,7 @@ extern "C" int pmap_reads_info(const pmap_reads_t *rd, uint32_t *n_reads, uint64
 extern "C" void pmap_reads_destroy(pmap_reads_t *rd) {
     if (!rd) return;
     rd->ascii.release(); rd->boff.release(); rd->woff.release(); rd->rlen.release(); rd->rflag.release();
-    rd->packed.release(); rd->wread.release();
+    rd->words.release(); rd->rmeta.release();
     delete rd;
 }
 
@@ -358,10 +373,8 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
     if (n_tiles) {
         kt.begin(KT_SKETCH);
 #define SKETCH_ARGS                                                                                                   \
-    rd->packed.as<uint32_t>(), rd->wread.as<uint32_t>(), rd->woff.as<uint32_t>(), rd->rlen.as<uint32_t>(),            \
-        rd->rflag.as<uint32_t>(), rd->n_words, n_tiles, w, k, idx->d_slots, idx->log2cap, res->mkmer.as<uint64_t>(),           \
-        res->ents.as<uint4>(), res->tile_nmini.as<uint32_t>(), res->tile_nent.as<uint32_t>(),                         \
-        res->tile_nhits.as<uint32_t>()
+    rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, idx->d_slots, idx->log2cap,            \
+        idx->d_filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>()
 #define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
     KLAUNCH(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
         // w = 14 (the default of pandora map) and w = 1 (dense sketches) have their own instantiations
@@ -382,25 +395,27 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         HIP_TRY(hipGetLastError());
     }
 
-    // ---- probe (unfused) + hit emission
-    if (last >= PMAP_STAGE_HITS && n_tiles) {
-        if (!fused) {
+    // ---- probe (unfused), totals and group offsets, hit emission
+    const uint32_t n_groups = (n_tiles + 63) / 64;
+    if (n_tiles) {
+        if (!fused && last >= PMAP_STAGE_HITS) {
             kt.begin(KT_PROBE);
-            KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(),
-                               res->tile_nent.as<uint32_t>(), n_tiles, idx->d_slots, idx->log2cap, res->ents.as<uint4>(),
-                               res->tile_nhits.as<uint32_t>());
+            KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(), n_tiles, idx->d_slots,
+                    idx->log2cap, idx->d_filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>());
             kt.end(KT_PROBE);
         }
         kt.begin(KT_TILE_SCAN);
-        if ((rc = device_scan<false>(res, res->tile_nmini.as<uint32_t>(), nullptr, n_tiles, &dc->n_mini))) return rc;
-        if ((rc = device_scan<false>(res, res->tile_nent.as<uint32_t>(), nullptr, n_tiles, &dc->n_ent))) return rc;
-        if ((rc = device_scan<false>(res, res->tile_nhits.as<uint32_t>(), res->tile_hoff.as<uint32_t>(), n_tiles,
-                                     &dc->n_hits)))
-            return rc;
+        KLAUNCH(group_reduce_kernel, dim3((n_groups + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles,
+                res->group_sum.as<uint4>());
+        KLAUNCH(group_spine_kernel, dim3(1), res->group_sum.as<uint4>(), n_groups, res->group_hoff.as<uint32_t>(),
+                &dc->n_mini, &dc->n_ent, &dc->n_hits);
         kt.end(KT_TILE_SCAN);
+        HIP_TRY(hipGetLastError());
+    }
+    if (last >= PMAP_STAGE_HITS && n_tiles) {
         kt.begin(KT_SCATTER);
-        KLAUNCH(scatter_group_kernel, dim3((n_tiles + 255) / 256),
-                           res->tile_nent.as<uint32_t>(), res->tile_hoff.as<uint32_t>(), n_tiles,
+        KLAUNCH(scatter_group_kernel, dim3((n_groups + 3) / 4),
+                           res->tile_cnt.as<uint4>(), res->group_hoff.as<uint32_t>(), n_tiles,
                            res->ents.as<uint4>(), idx->d_recs, res->hit_cap,
                            res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
                            res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
@@ -411,8 +426,6 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
                            res->hend.as<uint32_t>());
         kt.end(KT_SEG_BOUNDS);
         HIP_TRY(hipGetLastError());
-    } else if (n_tiles) {
-        if ((rc = device_scan<false>(res, res->tile_nmini.as<uint32_t>(), nullptr, n_tiles, &dc->n_mini))) return rc;
     }
 
     // ---- sort
@@ -535,10 +548,10 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
 
     // buffers whose size follows from the batch alone
     const uint32_t n_tiles = res->n_tiles;
-    const size_t tb = sizeof(uint32_t) * ((size_t) n_tiles + 1), sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS;
-    if ((rc = res->counters.ensure(sizeof(Counters))) || (rc = res->tile_nmini.ensure(tb)) ||
-        (rc = res->tile_nent.ensure(tb)) || (rc = res->tile_nhits.ensure(tb)) || (rc = res->tile_hoff.ensure(tb)) ||
-        (rc = res->ents.ensure(4 * sb)) || (rc = res->hstart.ensure(sizeof(uint32_t) * (rd->n_reads + 1))) ||
+    const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS, n_groups = ((size_t) n_tiles + 63) / 64;
+    if ((rc = res->counters.ensure(sizeof(Counters))) || (rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) ||
+        (rc = res->group_sum.ensure(sizeof(uint4) * (n_groups + 1))) ||
+        (rc = res->group_hoff.ensure(sizeof(uint32_t) * (n_groups + 1))) || (rc = res->ents.ensure(4 * sb)) || (rc = res->hstart.ensure(sizeof(uint32_t) * (rd->n_reads + 1))) ||
         (rc = res->hend.ensure(sizeof(uint32_t) * (rd->n_reads + 1))))
         return rc;
     if (!fused && (rc = res->mkmer.ensure(2 * sb))) return rc;
@@ -648,20 +661,23 @@ extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer,
     if (n == 0) return PMAP_OK;
     int rc;
     // gather the tile slots into one list
-    DevBuf moff, okm, ord, ops;
+    DevBuf nmini, moff, okm, ord, ops;
     auto done = [&](int code) {
-        moff.release(); okm.release(); ord.release(); ops.release();
+        nmini.release(); moff.release(); okm.release(); ord.release(); ops.release();
         return code;
     };
-    if ((rc = moff.ensure(sizeof(uint32_t) * (res->n_tiles + 1))) || (rc = okm.ensure(sizeof(uint64_t) * n)) ||
+    if ((rc = nmini.ensure(sizeof(uint32_t) * (res->n_tiles + 1))) ||
+        (rc = moff.ensure(sizeof(uint32_t) * (res->n_tiles + 1))) || (rc = okm.ensure(sizeof(uint64_t) * n)) ||
         (rc = ord.ensure(sizeof(uint32_t) * n)) || (rc = ops.ensure(sizeof(uint32_t) * n)) ||
         (rc = res->scratch_total.ensure(sizeof(unsigned long long))))
         return done(rc);
-    if ((rc = device_scan<false>(res, res->tile_nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles,
+    hipLaunchKernelGGL(tile_field_kernel, dim3((res->n_tiles + 255) / 256), dim3(256), 0, g_stream,
+                       res->tile_cnt.as<uint4>(), res->n_tiles, 0u, nmini.as<uint32_t>());
+    if ((rc = device_scan<false>(res, nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles,
                                  res->scratch_total.as<unsigned long long>())))
         return done(rc);
     hipLaunchKernelGGL(compact_minimizers_kernel, dim3((res->n_tiles + 3) / 4), dim3(256), 0, g_stream,
-                       res->tile_nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles, res->mkmer.as<uint64_t>(),
+                       nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles, res->mkmer.as<uint64_t>(),
                        res->ents.as<uint4>(), okm.as<uint64_t>(), ord.as<uint32_t>(),
                        ops.as<uint32_t>());
     if (hipStreamSynchronize(g_stream) != hipSuccess) return done(pmap_fail(PMAP_EHIP, "minimizer gather failed"));

@@ -1,8 +1,9 @@
 // Probe (unfused mode), hit emission and minimizer gather kernels of libpandora_amd (gfx950).
 // Included by pmap_kernels.hip.h only.
 //
-// The sketch kernel leaves, per wavefront tile g, `tile_nent[g]` entries in the tile's 256 slots
-// of `ents`: {read index, position | strand << 31, first record, record count}.
+// The sketch kernel leaves, per wavefront tile g, tile_cnt[g] = {minimizers, entries, hits, 0} and
+// the entries themselves in the tile's 512 slots of `ents`:
+// {read index, position | strand << 31, first record, record count}.
 #ifndef PMAP_EMIT_HIP_H
 #define PMAP_EMIT_HIP_H
 
@@ -21,26 +22,68 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v, uint32_t *total) {
 
 // probe as its own kernel (unfused mode): one wavefront per tile looks up the tile's minimizers
 // (add_read_hits' index->minhash.find, src/utils.cpp:175)
-__global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restrict__ mkmer,
-                                                         const uint32_t *__restrict__ tile_nent, uint32_t n_tiles,
+__global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restrict__ mkmer, uint32_t n_tiles,
                                                          const PmapSlot *__restrict__ slots, uint32_t log2cap,
-                                                         uint4 *__restrict__ ents, uint32_t *__restrict__ tile_nhits) {
+                                                         const uint32_t *__restrict__ filt, uint32_t fbits,
+                                                         uint4 *__restrict__ ents, uint4 *__restrict__ tile_cnt) {
     const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_tiles) return;
-    const uint32_t n = tile_nent[g];
+    const uint32_t n = tile_cnt[g].y;
     const uint64_t slot0 = (uint64_t) g * WAVE_POS;
     uint32_t mine = 0;
     for (uint32_t e = lane; e < n; e += 64) {
         uint32_t cnt, off;
-        table_lookup(slots, log2cap, mkmer[slot0 + e], &cnt, &off);
+        index_lookup(slots, log2cap, filt, fbits, mkmer[slot0 + e], &cnt, &off);
         uint32_t *ent = (uint32_t *) (ents + slot0 + e);
         ent[2] = off;
         ent[3] = cnt;
         mine += cnt;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
-    if (lane == 0) tile_nhits[g] = mine;
+    mine = wave_sum(mine);
+    if (lane == 0) ((uint32_t *) (tile_cnt + g))[2] = mine;
+}
+
+// Tiles are handled in groups of 64 (one wavefront of the scatter kernel per group).
+// group_sum[G] = sums of the tile counters over group G: one wavefront per group.
+__global__ __launch_bounds__(256) void group_reduce_kernel(const uint4 *__restrict__ tile_cnt, uint32_t n_tiles,
+                                                           uint4 *__restrict__ group_sum) {
+    const uint32_t lane = threadIdx.x & 63, G = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t t0 = G * 64;
+    if (t0 >= n_tiles) return;
+    const uint32_t t = t0 + lane;
+    uint4 c = make_uint4(0, 0, 0, 0);
+    if (t < n_tiles) c = tile_cnt[t];
+    const uint32_t x = wave_sum(c.x), y = wave_sum(c.y), z = wave_sum(c.z);
+    if (lane == 0) group_sum[G] = make_uint4(x, y, z, 0);
+}
+
+// one block: group_hoff = exclusive scan of the groups' hit counts; the three grand totals go to
+// the counters (minimizers, entries, hits)
+__global__ __launch_bounds__(256) void group_spine_kernel(const uint4 *__restrict__ group_sum, uint32_t n_groups,
+                                                          uint32_t *__restrict__ group_hoff,
+                                                          unsigned long long *__restrict__ n_mini,
+                                                          unsigned long long *__restrict__ n_ent,
+                                                          unsigned long long *__restrict__ n_hits) {
+    __shared__ uint32_t lds4[4];
+    unsigned long long cx = 0, cy = 0, cz = 0;
+    for (uint32_t base = 0; base < n_groups; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < n_groups) v = group_sum[i];
+        uint32_t tx, ty, tz;
+        block_scan_256(v.x, lds4, &tx);
+        block_scan_256(v.y, lds4, &ty);
+        const uint32_t ex = block_scan_256(v.z, lds4, &tz);
+        if (i < n_groups) group_hoff[i] = (uint32_t) (cz + ex);
+        cx += tx;
+        cy += ty;
+        cz += tz;
+    }
+    if (threadIdx.x == 0) {
+        *n_mini = cx;
+        *n_ent = cy;
+        *n_hits = cz;
+    }
 }
 
 // scatter: one wavefront per group of 64 tiles.  The group's entries are numbered consecutively
@@ -48,7 +91,7 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
 // search over the per-tile prefix sums held in the lanes, and writes the entry's hits (MinimizerHit
 // ctor, src/minihit.cpp:14-22) at the group's offset + the prefix sum of the record counts.
 __global__ __launch_bounds__(256) void scatter_group_kernel(
-    const uint32_t *__restrict__ tile_nent, const uint32_t *__restrict__ tile_hoff, uint32_t n_tiles,
+    const uint4 *__restrict__ tile_cnt, const uint32_t *__restrict__ group_hoff, uint32_t n_tiles,
     const uint4 *__restrict__ ents, const PmapRec *__restrict__ recs, uint32_t hit_cap,
     uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key, uint32_t *__restrict__ h_pos,
     uint32_t *__restrict__ h_rank, uint32_t *__restrict__ h_rec) {
@@ -56,11 +99,11 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
     const uint32_t t0 = G * 64;
     if (t0 >= n_tiles) return;
     const uint32_t t = t0 + lane;
-    const uint32_t n = t < n_tiles ? tile_nent[t] : 0;
+    const uint32_t n = t < n_tiles ? tile_cnt[t].y : 0;
     uint32_t E;
     const uint32_t estart = wave_scan(n, &E);
     if (E == 0) return;
-    uint32_t run = tile_hoff[t0];
+    uint32_t run = group_hoff[G];
     for (uint32_t base = 0; base < E; base += 64) {
         const uint32_t e = base + lane;
         // the tile of entry e: the largest T with estart[T] <= e
@@ -91,6 +134,13 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
         }
         run += tot;
     }
+}
+
+// one field (0 minimizers, 1 entries, 2 hits) of the tile counters as a plain array
+__global__ __launch_bounds__(256) void tile_field_kernel(const uint4 *__restrict__ tile_cnt, uint32_t n_tiles,
+                                                         uint32_t field, uint32_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_tiles) out[t] = ((const uint32_t *) (tile_cnt + t))[field];
 }
 
 // gathers the slotted minimizers into one contiguous list (only when a caller asks for them)

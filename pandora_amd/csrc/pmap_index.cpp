@@ -156,6 +156,19 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         while (idx->slots[s].key != PMAP_EMPTY_KEY) s = (s + 1) & capmask;
         idx->slots[s] = PmapSlot{ukeys[i], uoff[i], ucnt[i]};
     }
+    // presence filter: 8 bits per slot (16 per key at most), at most 2^24 bits (2 MiB) so that it stays
+    // in the L2 of every XCD; pointless once the keys would set more than a quarter of the bits
+    uint32_t fbits = std::min<uint32_t>(log2cap + 3, 24);
+    if (idx->n_keys * 4 > (1ull << fbits)) fbits = 0;
+    idx->filter_bits = fbits;
+    idx->filter.clear();
+    if (fbits) {
+        idx->filter.assign((size_t) 1 << (fbits - 5), 0u);
+        for (size_t i = 0; i < ukeys.size(); ++i) {
+            const uint32_t b = pmap_key_mix(ukeys[i]) >> (32 - fbits);
+            idx->filter[b >> 5] |= 1u << (b & 31);
+        }
+    }
     return PMAP_OK;
 }
 

@@ -31,8 +31,11 @@ static const uint64_t PMAP_EMPTY_KEY = ~0ULL;
 #else
 #define PMAP_HD
 #endif
+PMAP_HD static inline uint32_t pmap_key_mix(uint64_t key) {
+    return ((uint32_t) key ^ (uint32_t) (key >> 32)) * 2654435761u;
+}
 PMAP_HD static inline uint32_t pmap_slot_of(uint64_t key, uint32_t log2cap) {
-    return (((uint32_t) key ^ (uint32_t) (key >> 32)) * 2654435761u) >> (32 - log2cap);
+    return pmap_key_mix(key) >> (32 - log2cap);
 }
 
 struct pmap_index {
@@ -50,9 +53,13 @@ struct pmap_index {
     // host copies of the device structures (kept for checks and rebuilds)
     std::vector<PmapSlot> slots;
     std::vector<PmapRec> recs;
+    // presence filter: bit (pmap_key_mix(key) >> (32 - filter_bits)) is set for every key; 0 bits = no filter
+    uint32_t filter_bits = 0;
+    std::vector<uint32_t> filter;
     // device
     PmapSlot *d_slots = nullptr;
     PmapRec *d_recs = nullptr;
+    uint32_t *d_filter = nullptr;
     uint32_t *d_thr = nullptr;       // per-prg cluster size threshold of the last pmap_map call
     uint64_t device_bytes = 0;
     // parameters d_thr was computed for

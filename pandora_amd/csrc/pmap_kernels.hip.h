@@ -70,22 +70,6 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *lds4, u
     return woff + incl - v;
 }
 
-// one probe sequence of the open-addressing table: 16-byte slots, linear probing
-__device__ __forceinline__ void table_lookup(const PmapSlot *__restrict__ slots, uint32_t log2cap, uint64_t key,
-                                             uint32_t *cnt, uint32_t *off) {
-    const uint32_t capmask = (1u << log2cap) - 1;
-    uint32_t s = pmap_slot_of(key, log2cap);
-    *cnt = 0;
-    *off = 0;
-    for (uint32_t step = 0; step <= capmask; ++step) {   // at most half full: ends at an empty slot
-        const uint4 v = *(const uint4 *) (slots + s);
-        const uint64_t sk = ((uint64_t) v.y << 32) | v.x;
-        if (sk == key) { *off = v.z; *cnt = v.w; return; }
-        if (sk == PMAP_EMPTY_KEY) return;
-        s = (s + 1) & capmask;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // device-wide exclusive scan of uint32 (optionally of popcounts): reduce, spine, apply
 static const uint32_t SCAN_TILE = 2048;   // 256 threads x 8
@@ -165,8 +149,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict_
                                                      const uint64_t *__restrict__ boff,
                                                      const uint32_t *__restrict__ woff,
                                                      const uint32_t *__restrict__ rlen, uint32_t n_reads,
-                                                     uint32_t n_words, uint32_t *__restrict__ packed,
-                                                     uint32_t *__restrict__ wread, uint32_t *__restrict__ rflag) {
+                                                     uint32_t n_words, uint2 *__restrict__ words,
+                                                     uint32_t *__restrict__ rflag) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_words) return;
     // the read that owns word t: the largest r with woff[r] <= t (woff[n_reads] = n_words > t)
@@ -196,9 +180,18 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict_
             word |= code << (30 - 2 * i);
         }
     }
-    packed[t] = word;
-    wread[t] = r;
+    words[t] = make_uint2(word, r);
     if (bad) rflag[r] = 1;   // every writer stores the same value
+}
+
+// rmeta[r] = {first position of read r in the padded stream, its length, or 0 for a read with a
+// letter outside ACGT (such a read has no sketch, src/seq.cpp:48-52)}
+__global__ __launch_bounds__(256) void read_meta_kernel(const uint32_t *__restrict__ woff,
+                                                        const uint32_t *__restrict__ rlen,
+                                                        const uint32_t *__restrict__ rflag, uint32_t n_reads,
+                                                        uint2 *__restrict__ rmeta) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_reads) rmeta[r] = make_uint2(woff[r] * 16u, rflag[r] ? 0u : rlen[r]);
 }
 
 #include "pmap_sketch.hip.h"

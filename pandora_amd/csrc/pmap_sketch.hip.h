@@ -2,20 +2,22 @@
 // closed form, optionally fused with the index lookup of add_read_hits (src/utils.cpp:174-176).
 // Included by pmap_kernels.hip.h only.
 //
-// Every wavefront works alone on 64 quads (256 consecutive k-mer start positions) of the padded
+// Every wavefront works alone on 128 quads (512 consecutive k-mer start positions) of the padded
 // base stream and never meets a workgroup barrier: it stages the packed words it needs in its own
-// slice of LDS, hashes the 4 positions of one quad per lane, takes window minima and the "equals
-// the largest window minimum" test with 16-byte LDS reads, compacts the minimizers with ballots
-// and (fused mode) looks them up in the index at once.  With a = w-1 = 4f+p and edge = f + (p>0),
-// the first and last `edge` quads are halo: the wavefront emits the minimizers of its middle
-// 64 - 2*edge quads, and consecutive wavefronts overlap by the halo.
+// slice of LDS, hashes the 4 positions of two quads per lane (quads `lane` and `lane + 64`), takes
+// window minima and the "equals the largest window minimum" test with 16-byte LDS reads, compacts
+// the minimizers with ballots and (fused mode) looks them up in the index at once.  With
+// a = w-1 = 4f+p and edge = f + (p>0), the first and last `edge` quads are halo: the wavefront
+// emits the minimizers of its middle 128 - 2*edge quads, and consecutive wavefronts overlap by
+// the halo.
 #ifndef PMAP_SKETCH_HIP_H
 #define PMAP_SKETCH_HIP_H
 
-static const int WAVE_Q = 64;                      // quads per wavefront window
-static const int WAVE_POS = 4 * WAVE_Q;            // 256 positions, also the slot stride per wavefront
+static const int SK_NQ = 2;                        // quads per lane
+static const int WAVE_Q = 64 * SK_NQ;              // quads per wavefront window
+static const int WAVE_POS = 4 * WAVE_Q;            // 512 positions, also the slot stride per wavefront
 static const int SK_NW = WAVE_POS / 16 + 4;        // packed words held in LDS (window + misalignment + extraction overrun)
-static const int SK_MAX_W = 64;                    // edge <= 16 leaves at least 32 output quads
+static const int SK_MAX_W = 64;                    // edge <= 16 leaves at least 96 output quads
 static const uint32_t SK_NOKMER = 0xFFFFFFFFu;
 
 template <typename HT>
@@ -66,21 +68,52 @@ __device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b) {
     return r;
 }
 
-// src/inthash.cpp:115-125 for a mask of at most 30 bits (k <= 15): every step is masked to 2k
-// bits, so arithmetic modulo 2^32 gives the same low 2k bits as modulo 2^64, and the last step
-// (key + (key << 31)) & mask leaves key unchanged.
-__device__ __forceinline__ uint32_t hash64_u32(uint32_t key, uint32_t mask) {
-    key = lshl_add<21>(key, ~key) & mask;
-    key = key ^ key >> 24;
-    key = lshl_add<8>(key, lshl_add<3>(key, key)) & mask;
-    key = key ^ key >> 14;
-    key = lshl_add<4>(key, lshl_add<2>(key, key)) & mask;
-    key = key ^ key >> 28;
-    return key;
+// Bit widths of the three right shifts of hash64 under a 2k-bit mask: (key & mask) >> s has
+// max(2k - s, 0) significant bits.
+struct HashWidths {
+    uint32_t w24, w14, w28;
+};
+__device__ __forceinline__ HashWidths hash_widths(uint32_t k) {
+    const uint32_t kb = 2 * k;
+    HashWidths r;
+    r.w24 = kb > 24 ? kb - 24 : 0;
+    r.w14 = kb > 14 ? kb - 14 : 0;
+    r.w28 = kb > 28 ? kb - 28 : 0;
+    return r;
 }
 
-__device__ __forceinline__ uint32_t hash_any(uint32_t key, uint32_t mask) { return hash64_u32(key, mask); }
-__device__ __forceinline__ uint64_t hash_any(uint64_t key, uint64_t mask) { return hash64_dev<uint64_t>(key, mask); }
+// src/inthash.cpp:115-125 for a mask of at most 30 bits (k <= 15).  Additions and left shifts
+// carry only upwards, so the low 2k bits of every step are right whatever sits above them: the
+// input need not be masked, each `key ^ key >> s` takes its shifted operand with a bit-field
+// extract of the masked part, and the mask itself is applied once at the end.  The last step of
+// the reference, (key + (key << 31)) & mask, leaves a <= 30-bit key unchanged.
+__device__ __forceinline__ uint32_t hash64_u32(uint32_t key, uint32_t mask, const HashWidths &hw) {
+    key = lshl_add<21>(key, ~key);
+    key ^= __builtin_amdgcn_ubfe(key, 24u, hw.w24);
+    key = lshl_add<8>(key, lshl_add<3>(key, key));
+    key ^= __builtin_amdgcn_ubfe(key, 14u, hw.w14);
+    key = lshl_add<4>(key, lshl_add<2>(key, key));
+    key ^= __builtin_amdgcn_ubfe(key, 28u, hw.w28);
+    return key & mask;
+}
+
+// reverse complement of 16 bases held in 32 bits (2 bits per base, first base on top)
+__device__ __forceinline__ uint32_t revcomp16(uint32_t v) {
+    const uint32_t r = __brev(v);   // reverses the bases and swaps the two bits of each
+    return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+}
+
+// sum over the wavefront, valid in every lane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    // inclusive scan inside each row of 16 lanes, then row totals carried across rows
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
 
 // Minimum over the a+1 positions ending at each of the 4 positions of quad Q (backward window),
 // a = 4f + p >= 4.  Window of position 4Q+j starts at 4(Q-f) + j - p.
@@ -139,18 +172,43 @@ __device__ __forceinline__ Quad<HT> window_max_fwd(const HT *L, int Q, int f, in
     return out;
 }
 
+// One lookup of the index: the presence filter (one bit per 2^-fbits of the home-slot hash range,
+// small enough to stay in L2) turns most absent keys away before the slot table is touched.
+__device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots, uint32_t log2cap,
+                                             const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t key,
+                                             uint32_t *cnt, uint32_t *off) {
+    *cnt = 0;
+    *off = 0;
+    const uint32_t hm = pmap_key_mix(key);
+    if (fbits) {
+        const uint32_t b = hm >> (32 - fbits);
+        if (!((filt[b >> 5] >> (b & 31)) & 1u)) return;
+    }
+    const uint32_t capmask = (1u << log2cap) - 1;
+    uint32_t s = hm >> (32 - log2cap);
+    for (uint32_t step = 0; step <= capmask; ++step) {   // at most half full: ends at an empty slot
+        const uint4 v = *(const uint4 *) (slots + s);
+        const uint64_t sk = ((uint64_t) v.y << 32) | v.x;
+        if (sk == key) { *off = v.z; *cnt = v.w; return; }
+        if (sk == PMAP_EMPTY_KEY) return;
+        s = (s + 1) & capmask;
+    }
+}
+
 // FUSED = false: every minimizer of the wavefront goes to its slots of (mkmer, ents).
 // FUSED = true : every minimizer is looked up in the index at once; only those with records go
 //                to the slots of ents; the wavefront's hit count is kept.
 // WC > 0 fixes w at compile time (window shapes unroll); WC = 0 takes w from the argument.
-// Wavefront g owns output positions [g * 4 * out_q, (g + 1) * 4 * out_q), out_q = 64 - 2 * edge.
+// Wavefront g owns output positions [g * 4 * out_q, (g + 1) * 4 * out_q), out_q = 128 - 2 * edge.
+// words[t] = {16 packed bases, read index}; rmeta[r] = {first position of read r in the padded
+// stream, its length or 0 if it has a letter outside ACGT}.
+// tile_cnt[g] = {minimizers, entries, hits, 0} of the wavefront.
 template <typename HT, bool FUSED, int WC>
 __global__ __launch_bounds__(256) void sketch_wave_kernel(
-    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ wread, const uint32_t *__restrict__ woff,
-    const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ rflag, uint32_t n_words, uint32_t n_tiles,
-    uint32_t w_arg, uint32_t k, const PmapSlot *__restrict__ slots, uint32_t log2cap, uint64_t *__restrict__ mkmer,
-    uint4 *__restrict__ ents, uint32_t *__restrict__ tile_nmini, uint32_t *__restrict__ tile_nent,
-    uint32_t *__restrict__ tile_nhits) {
+    const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
+    uint32_t w_arg, uint32_t k, const PmapSlot *__restrict__ slots, uint32_t log2cap,
+    const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
+    uint4 *__restrict__ tile_cnt) {
     const uint32_t w = WC ? (uint32_t) WC : w_arg;
     __shared__ uint32_t sW[4][SK_NW], sStart[4][SK_NW], sLen[4][SK_NW], sRead[4][SK_NW];
     __shared__ __align__(16) HT sH[4][WAVE_POS];
@@ -170,14 +228,18 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     const int out_q = WAVE_Q - 2 * edge;
     const int64_t P0 = (int64_t) g * (4 * out_q) - 4 * edge;   // global position of quad 0, a multiple of 4
     const int64_t wbase = P0 >> 4;                              // floor: P0 is negative for g = 0
+    const uint32_t off0 = (uint32_t) (P0 & 15);                 // 0, 4, 8 or 12
+    const uint32_t P0lo = (uint32_t) P0;                        // positions are below 2^32; wrapping is harmless
     if (lane < SK_NW) {
         const int64_t wi = wbase + lane;
         uint32_t word = 0, ms = 0, ml = 0, ri = 0;
         if (wi >= 0 && wi < (int64_t) n_words) {
-            word = packed[wi];
-            ri = wread[wi];
-            ms = woff[ri] * 16;
-            ml = rflag[ri] ? 0 : rlen[ri];
+            const uint2 wd = words[wi];
+            word = wd.x;
+            ri = wd.y;
+            const uint2 rm = rmeta[ri];
+            ms = rm.x;
+            ml = rm.y;
             if (ml + 1 < w + k) ml = 0;             // too short to sketch (src/seq.cpp:92-94)
         }
         W[lane] = word;
@@ -185,153 +247,168 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
         mlen[lane] = ml;
         wr[lane] = ri;
     }
+    if (lane < 2) stq(Lv, WAVE_Q + lane, Quad<HT>{{0, 0, 0, 0}});
     wave_lds_sync();
 
-    // ---- canonical hashes of the lane's quad (src/seq.cpp:41-47, 109-111)
+    // ---- canonical hashes of the lane's quads (src/seq.cpp:41-47, 109-111)
     const HT mask = (HT) (((uint64_t) 1 << (2 * k)) - 1);
-    const int64_t pq = P0 + 4 * lane;               // global position of the quad's first base
-    const int wi = (int) ((pq >> 4) - wbase);
-    const uint32_t len = mlen[wi];
-    const uint32_t rd = wr[wi];
-    Quad<HT> own;
-    own.v[0] = own.v[1] = own.v[2] = own.v[3] = INVALID;
-    uint32_t jj[4] = {SK_NOKMER, SK_NOKMER, SK_NOKMER, SK_NOKMER};
-    if (len != 0) {
-        const uint32_t j0 = (uint32_t) pq - mstart[wi];
-        const uint32_t sh0 = (uint32_t) (pq & 15) * 2;          // 0, 8, 16 or 24
+    const HashWidths hw = hash_widths(k);
+    // byte selector that funnels the 4 bytes starting (lane's misalignment) bytes into a word pair;
+    // the misalignment is the same for both quads of the lane (they are 64 quads = 16 words apart)
+    const uint32_t mis = ((uint32_t) lane + (off0 >> 2)) & 3u;     // quad inside its packed word
+    uint32_t bsel = mis | (mis << 8);
+    bsel = 0x07060504u - (bsel | (bsel << 16));
+    Quad<HT> own[SK_NQ];
+    uint32_t jj[SK_NQ][4];
+#pragma unroll
+    for (int hq = 0; hq < SK_NQ; ++hq) {
+        const int Q = lane + 64 * hq;
+        const int wi = (int) ((4u * (uint32_t) Q + off0) >> 4);
+        const uint32_t len = mlen[wi];
+        const uint32_t j0 = P0lo + 4u * (uint32_t) Q - mstart[wi];     // position of the quad inside its read
+        // k-mer j0 + j exists iff j <= lim
+        const int lim = len ? (int) (len - k - j0) : -1;
         const uint32_t w0 = W[wi], w1 = W[wi + 1], w2 = W[wi + 2];
         // 64 stream bits starting at the quad's first base
-        const uint32_t x0 = sh0 ? (w0 << sh0) | (w1 >> (32 - sh0)) : w0;
-        const uint32_t x1 = sh0 ? (w1 << sh0) | (w2 >> (32 - sh0)) : w1;
-        uint32_t x2 = 0;                                        // the next 32 bits, only needed for k > 15
-        if (sizeof(HT) == 8) {
-            const uint32_t w3 = W[wi + 3];
-            x2 = sh0 ? (w2 << sh0) | (w3 >> (32 - sh0)) : w2;
-        }
-        HT rc = 0;
+        const uint32_t x0 = __builtin_amdgcn_perm(w0, w1, bsel), x1 = __builtin_amdgcn_perm(w1, w2, bsel);
+        if constexpr (sizeof(HT) == 4) {
+            // k <= 15.  With Y = reverse complement of the 32 bases x0:x1, the reverse complement of
+            // the k-mer at base j is (Y >> 2j) & mask; hash64_u32 ignores what lies above the mask.
+            const uint32_t ylo = revcomp16(x0), yhi = revcomp16(x1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            HT fwd;
-            if (sizeof(HT) == 4) {
-                // k <= 15: 2k bits at bit offset 2j <= 6 of x0:x1
-                const uint32_t top = j ? (x0 << (2 * j)) | (x1 >> (32 - 2 * j)) : x0;
-                fwd = (HT) (top >> (32 - 2 * k));
-            } else {
-                const uint64_t x = ((uint64_t) x0 << 32) | x1;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t top = j ? __builtin_amdgcn_alignbit(x0, x1, 32 - 2 * j) : x0;
+                const uint32_t fwd = top >> (32 - 2 * k);
+                const uint32_t rc = j ? __builtin_amdgcn_alignbit(yhi, ylo, 2 * j) : ylo;
+                const uint32_t hf = hash64_u32(fwd, mask, hw), hr = hash64_u32(rc, mask, hw);
+                const bool ok = j <= lim;
+                // hashes are below 2^30: the sign of hr - hf tells hf > hr; strand = (hf <= hr)
+                const uint32_t ps = (j0 + j) | (~(hr - hf) & 0x80000000u);
+                own[hq].v[j] = ok ? tmin(hf, hr) : INVALID;
+                jj[hq][j] = ok ? ps : SK_NOKMER;
+            }
+        } else {
+            const uint32_t w3 = W[wi + 3];
+            const uint32_t x2 = __builtin_amdgcn_perm(w2, w3, bsel);   // the next 32 bits
+            const uint64_t x = ((uint64_t) x0 << 32) | x1;
+            uint64_t rc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 uint64_t z = x << (2 * j);
                 if (j) z |= (uint64_t) (x2 >> (32 - 2 * j));
-                fwd = (HT) (z >> (64 - 2 * k));
+                const uint64_t fwd = z >> (64 - 2 * k);
+                // reverse complement: from scratch for the first k-mer, then one base at a time (src/seq.cpp:44)
+                if (j == 0) rc = revcomp_dev(fwd, k);
+                else rc = (rc >> 2) | ((uint64_t) (3u ^ ((uint32_t) fwd & 3u)) << (2 * k - 2));
+                const uint64_t hf = hash64_dev<uint64_t>(fwd, mask), hr = hash64_dev<uint64_t>(rc, mask);
+                const bool ok = j <= lim;
+                own[hq].v[j] = ok ? tmin(hf, hr) : INVALID;
+                jj[hq][j] = ok ? ((j0 + j) | ((hf <= hr ? 1u : 0u) << 31)) : SK_NOKMER;
             }
-            // reverse complement: from scratch for the first k-mer, then one base at a time (src/seq.cpp:44)
-            if (j == 0) rc = (HT) revcomp_dev(fwd, k);
-            else rc = (HT) ((rc >> 2) | ((HT) (3u ^ ((uint32_t) fwd & 3u)) << (2 * k - 2)));
-            const HT hf = hash_any(fwd, mask), hr = hash_any(rc, mask);
-            const bool ok = j0 + j + k <= len;
-            own.v[j] = ok ? tmin(hf, hr) : INVALID;
-            jj[j] = ok ? ((j0 + j) | ((hf <= hr ? 1u : 0u) << 31)) : SK_NOKMER;
         }
+        stq(h, Q, own[hq]);
+        *(uint4 *) (jv + 4 * Q) = make_uint4(jj[hq][0], jj[hq][1], jj[hq][2], jj[hq][3]);
     }
-    stq(h, lane, own);
-    *(uint4 *) (jv + 4 * lane) = make_uint4(jj[0], jj[1], jj[2], jj[3]);
-    if (lane < 2) stq(Lv, WAVE_Q + lane, Quad<HT>{{0, 0, 0, 0}});   // the forward window of the last quads may read 2 quads past the end
     wave_lds_sync();
 
     // ---- Lv[t] = minimum of the full window ending at k-mer t, 0 if that window is not inside one read
-    {
+#pragma unroll
+    for (int hq = 0; hq < SK_NQ; ++hq) {
+        const int Q = lane + 64 * hq;
+        const int Qc = Q < edge ? edge : Q;         // halo quads: any in-range window will do, their result is never used
         Quad<HT> m;
-        m.v[0] = m.v[1] = m.v[2] = m.v[3] = 0;
-        if (lane >= edge) {
-            if (a >= 4) {
-                m = window_min_back<HT>(h, lane, f, p);
-            } else {
+        if (a >= 4) {
+            m = window_min_back<HT>(h, Qc, f, p);
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    HT x = own.v[j];
-                    for (int d = 1; d <= a; ++d) x = tmin(x, h[4 * lane + j - d]);
-                    m.v[j] = x;
-                }
+            for (int j = 0; j < 4; ++j) {
+                HT x = h[4 * Qc + j];
+                for (int d = 1; d <= a; ++d) x = tmin(x, h[4 * Qc + j - d]);
+                m.v[j] = x;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (jj[j] == SK_NOKMER || (jj[j] & 0x7FFFFFFFu) < (uint32_t) a) m.v[j] = 0;
         }
-        stq(Lv, lane, m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (jj[hq][j] == SK_NOKMER || (jj[hq][j] & 0x7FFFFFFFu) < (uint32_t) a) m.v[j] = 0;
+        stq(Lv, Q, m);
     }
     wave_lds_sync();
 
     // ---- k-mer i is a minimizer iff it equals the largest of the minima of the windows containing it
-    bool fl[4] = {false, false, false, false};
-    if (lane >= edge && lane < WAVE_Q - edge) {
+    bool fl[SK_NQ][4];
+#pragma unroll
+    for (int hq = 0; hq < SK_NQ; ++hq) {
+        const int Q = lane + 64 * hq;
+        const bool inr = (uint32_t) (Q - edge) < (uint32_t) out_q;
+        const int Qc = Q > WAVE_Q - 1 - edge ? WAVE_Q - 1 - edge : Q;
         Quad<HT> mx;
         if (a >= 4) {
-            mx = window_max_fwd<HT>(Lv, lane, f, p);
+            mx = window_max_fwd<HT>(Lv, Qc, f, p);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                HT x = Lv[4 * lane + j];
-                for (int d = 1; d <= a; ++d) x = tmax(x, Lv[4 * lane + j + d]);
+                HT x = Lv[4 * Qc + j];
+                for (int d = 1; d <= a; ++d) x = tmax(x, Lv[4 * Qc + j + d]);
                 mx.v[j] = x;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fl[j] = jj[j] != SK_NOKMER && mx.v[j] == own.v[j];
+        for (int j = 0; j < 4; ++j) fl[hq][j] = inr && jj[hq][j] != SK_NOKMER && mx.v[j] == own[hq].v[j];
     }
-    wave_lds_sync();                                // every lane has read its quads: the arrays can be reused
+    wave_lds_sync();                                // every lane has read Lv: it becomes the list of minimizer positions
 
-    // ---- compaction in position order with ballots; Lv / jv / h become the staging lists
-    HT *c_h = Lv;
-    uint32_t *c_ps = jv, *c_rd = (uint32_t *) h;
-    uint32_t n = 0, o = 0;
+    // ---- compaction in position order with ballots: list[e] = index (4 * quad + j) of the e-th minimizer
+    uint32_t *list = (uint32_t *) Lv;
+    uint32_t n = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned long long b = __ballot(fl[j]);
-        // flags of lower lanes are earlier positions whatever their j
-        o += __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
-        n += __popcll(b);
-    }
+    for (int hq = 0; hq < SK_NQ; ++hq) {
+        uint32_t o = n, c = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (fl[j]) {
-            c_h[o] = own.v[j];
-            c_ps[o] = jj[j];
-            c_rd[o] = rd;
-            ++o;
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long b = __ballot(fl[hq][j]);
+            // flags of lower lanes are earlier positions whatever their j
+            o += __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
+            c += __popcll(b);
         }
+        n += c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (fl[hq][j]) list[o++] = 4u * (uint32_t) (lane + 64 * hq) + j;
+    }
     wave_lds_sync();
 
     const uint64_t slot0 = (uint64_t) g * WAVE_POS;
-    if (!FUSED) {
-        for (uint32_t e = lane; e < n; e += 64) {
-            mkmer[slot0 + e] = (uint64_t) c_h[e];
-            ents[slot0 + e] = make_uint4(c_rd[e], c_ps[e], 0, 0);
+    uint32_t nent = 0, hits = 0;
+    for (uint32_t base = 0; base < n; base += 64) {     // n is wave-uniform
+        const uint32_t e = base + lane;
+        uint32_t cnt = 0, off = 0, ps = 0, rd = 0;
+        HT hv = 0;
+        if (e < n) {
+            const uint32_t i = list[e];
+            hv = h[i];
+            ps = jv[i];
+            rd = wr[(i + off0) >> 4];
         }
-        if (lane == 0) {
-            tile_nmini[g] = n;
-            tile_nent[g] = n;
-        }
-    } else {
-        uint32_t nent = 0, hits = 0;
-        for (uint32_t base = 0; base < n; base += 64) {     // n is wave-uniform
-            const uint32_t e = base + lane;
-            uint32_t cnt = 0, off = 0;
-            if (e < n) table_lookup(slots, log2cap, (uint64_t) c_h[e], &cnt, &off);
+        if (!FUSED) {
+            if (e < n) {
+                mkmer[slot0 + e] = (uint64_t) hv;
+                ents[slot0 + e] = make_uint4(rd, ps, 0, 0);
+            }
+        } else {
+            if (e < n) index_lookup(slots, log2cap, filt, fbits, (uint64_t) hv, &cnt, &off);
             const unsigned long long b = __ballot(cnt != 0);
             if (cnt) {
                 const uint64_t s = slot0 + nent +
                                    __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
-                ents[s] = make_uint4(c_rd[e], c_ps[e], off, cnt);
+                ents[s] = make_uint4(rd, ps, off, cnt);
             }
             nent += __popcll(b);
             hits += cnt;
         }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) hits += __shfl_xor(hits, d);
-        if (lane == 0) {
-            tile_nmini[g] = n;
-            tile_nent[g] = nent;
-            tile_nhits[g] = hits;
-        }
     }
+    if (FUSED) hits = wave_sum(hits);
+    else nent = n;
+    if (lane == 0) tile_cnt[g] = make_uint4(n, nent, hits, 0);
 }
 
 #endif
