@@ -25,9 +25,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 # kernels of each phase (names of pmap_kernel_name)
 PHASES = {
     "sketch": ["sketch"],          # fused mode: the index lookup runs inside this kernel
-    "probe": ["probe", "tile_scan", "scatter", "seg_bounds"],
+    "probe": ["probe", "scatter"],
     "sort": ["sort_rank"],
-    "cluster": ["cluster_flags", "cluster_scan", "cluster_starts", "cluster_table", "kept_scan", "kept_gather"],
+    "cluster": ["cluster_cut", "cluster_keep"],
 }
 
 

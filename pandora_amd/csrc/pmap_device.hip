@@ -79,14 +79,17 @@ struct DevBuf {
 };
 
 // counters kept in device memory for the whole pipeline, read back once per call
+static const int TOTAL_LANES = 64;   // batch totals are accumulated in 64 separate words each, summed by the host
 struct Counters {
-    unsigned long long n_mini;    // minimizers of the batch
-    unsigned long long n_ent;     // entries handed to the scatter (all minimizers, or only those with hits)
-    unsigned long long n_hits;
+    unsigned long long n_hits;    // hits of the batch as the chained prefix sum gives them (low 32 bits exact)
     unsigned long long n_cl;      // clusters before the size threshold
     unsigned long long n_kept;    // clusters kept
-    unsigned long long pad[3];
+    uint32_t fail;                // a chained prefix sum gave up waiting
+    uint32_t pad[9];
+    // [0] minimizers, [1] entries handed to the scatter (all minimizers, or only those with hits), [2] hits
+    unsigned long long totals[3][TOTAL_LANES];
 };
+static_assert(sizeof(Counters) % 16 == 0, "Counters is the head of the state block");
 
 #include "pmap_kernels.hip.h"
 
@@ -106,13 +109,9 @@ struct pmap_reads {
     }
 };
 
-enum {
-    KT_SKETCH = 0, KT_PROBE, KT_TILE_SCAN, KT_SCATTER, KT_SEG_BOUNDS, KT_SORT, KT_CLUSTER_FLAGS, KT_CLUSTER_SCAN,
-    KT_CLUSTER_STARTS, KT_CLUSTER_TABLE, KT_KEPT_SCAN, KT_KEPT_GATHER, KT_COUNT
-};
+enum { KT_SKETCH = 0, KT_PROBE, KT_SCATTER, KT_SORT, KT_CLUSTER_CUT, KT_CLUSTER_KEEP, KT_COUNT };
 static const char *kernel_names[PMAP_N_KERNELS] = {
-    "sketch", "probe", "tile_scan", "scatter", "seg_bounds", "sort_rank", "cluster_flags", "cluster_scan",
-    "cluster_starts", "cluster_table", "kept_scan", "kept_gather", "", "", "", ""};
+    "sketch", "probe", "scatter", "sort_rank", "cluster_cut", "cluster_keep", "", "", "", "", "", "", "", "", "", ""};
 
 struct pmap_result {
     pmap_counts_t counts;
@@ -121,16 +120,19 @@ struct pmap_result {
     bool have_minimizers = false;     // the last run kept every minimizer (unfused)
     float kernel_ms[PMAP_N_KERNELS];
     uint32_t hit_cap = 0, cl_cap = 0;
-    DevBuf counters;
+    // state block, zeroed before every run: Counters, then the 8-byte words of the three chained prefix sums
+    DevBuf state;
+    uint32_t n_sblk = 0, n_ablk = 0, n_bblk = 0;   // blocks of the scatter, cluster cut and cluster keep kernels
     // per tile
-    DevBuf tile_cnt, group_sum, group_hoff, bsum, scratch_total;
+    DevBuf tile_cnt, bsum, scratch_total;
     // tile-slotted entries
     DevBuf mkmer, ents;
     // hits before / after sort
-    DevBuf h_read, h_key, h_pos, h_rank, h_rec, hstart, hend;
+    DevBuf h_read, h_key, h_pos, h_rank, h_rec;
+    DevBuf hbounds;   // per read: first hit, then ~(one past the last hit); all-ones before every run
     DevBuf s_read, s_key, s_pos, s_rank, s_rec;
     // clusters
-    DevBuf cflags, coffs, cstart, c_size, c_read, c_key, c_first, c_last, c_rank, kflags, koffs, kidx, k_rows;
+    DevBuf cstart, k_rows;
     DevBuf thr;
     std::vector<uint32_t> thr_host;
     const pmap_index *thr_idx = nullptr;
@@ -139,10 +141,8 @@ struct pmap_result {
     hipEvent_t kev[2 * PMAP_N_KERNELS];
     bool events = false;
     std::vector<DevBuf *> all() {
-        return {&counters, &tile_cnt, &group_sum, &group_hoff, &bsum, &scratch_total, &mkmer, &ents,
-                &h_read, &h_key, &h_pos, &h_rank, &h_rec, &hstart, &hend, &s_read, &s_key,
-                &s_pos, &s_rank, &s_rec, &cflags, &coffs, &cstart, &c_size, &c_read, &c_key, &c_first, &c_last,
-                &c_rank, &kflags, &koffs, &kidx, &k_rows, &thr};
+        return {&state, &tile_cnt, &bsum, &scratch_total, &mkmer, &ents, &h_read, &h_key, &h_pos, &h_rank, &h_rec,
+                &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &cstart, &k_rows, &thr};
     }
 };
 
@@ -365,8 +365,17 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
     const uint32_t k = prm->k, w = prm->w;
     const bool k32 = k <= 15;
     const uint32_t n_tiles = res->n_tiles;
-    Counters *dc = res->counters.as<Counters>();
-    HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), g_stream));
+    // state block: counters + one 8-byte word per block of each chained prefix sum
+    res->n_sblk = (n_tiles + 255) / 256;
+    res->n_ablk = res->hit_cap / CUT_BLOCK;
+    res->n_bblk = res->cl_cap / 256;
+    const size_t state_bytes =
+        (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_sblk + res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
+    if ((rc = res->state.ensure(state_bytes))) return rc;
+    Counters *dc = res->state.as<Counters>();
+    unsigned long long *gran_s = (unsigned long long *) (dc + 1), *gran_a = gran_s + res->n_sblk,
+                       *gran_b = gran_a + res->n_ablk;
+    HIP_TRY(hipMemsetAsync(dc, 0, state_bytes, g_stream));
     g_kt = &kt;
 
     // ---- sketch (+ probe when fused)
@@ -395,36 +404,23 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         HIP_TRY(hipGetLastError());
     }
 
-    // ---- probe (unfused), totals and group offsets, hit emission
-    const uint32_t n_groups = (n_tiles + 63) / 64;
+    // ---- probe (unfused), batch totals, hit emission
     if (n_tiles) {
-        if (!fused && last >= PMAP_STAGE_HITS) {
+        const bool emit = last >= PMAP_STAGE_HITS;
+        if (!fused && emit) {
             kt.begin(KT_PROBE);
             KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(), n_tiles, idx->d_slots,
                     idx->log2cap, idx->d_filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>());
             kt.end(KT_PROBE);
         }
-        kt.begin(KT_TILE_SCAN);
-        KLAUNCH(group_reduce_kernel, dim3((n_groups + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles,
-                res->group_sum.as<uint4>());
-        KLAUNCH(group_spine_kernel, dim3(1), res->group_sum.as<uint4>(), n_groups, res->group_hoff.as<uint32_t>(),
-                &dc->n_mini, &dc->n_ent, &dc->n_hits);
-        kt.end(KT_TILE_SCAN);
-        HIP_TRY(hipGetLastError());
-    }
-    if (last >= PMAP_STAGE_HITS && n_tiles) {
+        if (emit)
+            HIP_TRY(hipMemsetAsync(res->hbounds.p, 0xFF, sizeof(uint32_t) * 2 * ((size_t) rd->n_reads + 1), g_stream));
         kt.begin(KT_SCATTER);
-        KLAUNCH(scatter_group_kernel, dim3((n_groups + 3) / 4),
-                           res->tile_cnt.as<uint4>(), res->group_hoff.as<uint32_t>(), n_tiles,
-                           res->ents.as<uint4>(), idx->d_recs, res->hit_cap,
-                           res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
-                           res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
+        KLAUNCH(scatter_group_kernel, dim3(res->n_sblk), res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
+                idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, gran_s, rd->n_reads + 1, res->hbounds.as<uint32_t>(),
+                res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
+                res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
         kt.end(KT_SCATTER);
-        kt.begin(KT_SEG_BOUNDS);
-        KLAUNCH(seg_bounds_kernel, dim3(res->hit_cap / 256),
-                           res->h_read.as<uint32_t>(), &dc->n_hits, res->hit_cap, res->hstart.as<uint32_t>(),
-                           res->hend.as<uint32_t>());
-        kt.end(KT_SEG_BOUNDS);
         HIP_TRY(hipGetLastError());
     }
 
@@ -434,7 +430,7 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         KLAUNCH(sort_rank_kernel, dim3(res->hit_cap / 256), &dc->n_hits,
                            res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(),
                            res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(),
-                           res->hstart.as<uint32_t>(), res->hend.as<uint32_t>(), res->s_read.as<uint32_t>(),
+                           res->hbounds.as<uint32_t>(), rd->n_reads + 1, res->s_read.as<uint32_t>(),
                            res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(),
                            res->s_rec.as<uint32_t>());
         kt.end(KT_SORT);
@@ -443,44 +439,16 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
 
     // ---- cluster
     if (last >= PMAP_STAGE_CLUSTER && n_tiles) {
-        const uint32_t n_cfw = res->hit_cap / 32, n_kfw = res->cl_cap / 32;
-        kt.begin(KT_CLUSTER_FLAGS);
-        KLAUNCH(cluster_flags_kernel, dim3(res->hit_cap / 256), &dc->n_hits,
-                           res->hit_cap, res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
-                           res->s_pos.as<uint32_t>(), (int) prm->max_diff, res->cflags.as<unsigned long long>());
-        kt.end(KT_CLUSTER_FLAGS);
-        kt.begin(KT_CLUSTER_SCAN);
-        if ((rc = device_scan<true>(res, res->cflags.as<uint32_t>(), res->coffs.as<uint32_t>(), n_cfw, &dc->n_cl)))
-            return rc;
-        kt.end(KT_CLUSTER_SCAN);
-        kt.begin(KT_CLUSTER_STARTS);
-        KLAUNCH(bit_positions_kernel, dim3((n_cfw + 255) / 256),
-                           res->cflags.as<uint32_t>(), res->coffs.as<uint32_t>(), n_cfw, res->cl_cap,
-                           res->cstart.as<uint32_t>());
-        kt.end(KT_CLUSTER_STARTS);
-        kt.begin(KT_CLUSTER_TABLE);
-        KLAUNCH(cluster_table_kernel, dim3(res->cl_cap / 256), &dc->n_cl,
-                           res->cl_cap, &dc->n_hits, res->hit_cap, res->cstart.as<uint32_t>(),
-                           res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(),
-                           res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), res->c_size.as<uint32_t>(),
-                           res->c_read.as<uint32_t>(), res->c_key.as<uint32_t>(), res->c_first.as<uint32_t>(),
-                           res->c_last.as<uint32_t>(), res->c_rank.as<uint32_t>(),
-                           res->kflags.as<unsigned long long>());
-        kt.end(KT_CLUSTER_TABLE);
-        kt.begin(KT_KEPT_SCAN);
-        if ((rc = device_scan<true>(res, res->kflags.as<uint32_t>(), res->koffs.as<uint32_t>(), n_kfw, &dc->n_kept)))
-            return rc;
-        kt.end(KT_KEPT_SCAN);
-        kt.begin(KT_KEPT_GATHER);
-        KLAUNCH(bit_positions_kernel, dim3((n_kfw + 255) / 256),
-                           res->kflags.as<uint32_t>(), res->koffs.as<uint32_t>(), n_kfw, res->cl_cap,
-                           res->kidx.as<uint32_t>());
-        KLAUNCH(cluster_gather_kernel, dim3(res->cl_cap / 256), &dc->n_kept,
-                           res->cl_cap, res->kidx.as<uint32_t>(), res->cstart.as<uint32_t>(),
-                           res->c_size.as<uint32_t>(), res->c_read.as<uint32_t>(), res->c_key.as<uint32_t>(),
-                           res->c_first.as<uint32_t>(), res->c_last.as<uint32_t>(), res->c_rank.as<uint32_t>(),
-                           res->k_rows.as<uint32_t>());
-        kt.end(KT_KEPT_GATHER);
+        kt.begin(KT_CLUSTER_CUT);
+        KLAUNCH(cluster_cut_kernel, dim3(res->n_ablk), dc, res->hit_cap, res->s_read.as<uint32_t>(),
+                res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), (int) prm->max_diff, gran_a, res->cl_cap,
+                res->cstart.as<uint32_t>());
+        kt.end(KT_CLUSTER_CUT);
+        kt.begin(KT_CLUSTER_KEEP);
+        KLAUNCH(cluster_keep_kernel, dim3(res->n_bblk), dc, res->cl_cap, res->hit_cap, res->cstart.as<uint32_t>(),
+                res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(),
+                res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), gran_b, res->k_rows.as<uint32_t>());
+        kt.end(KT_CLUSTER_KEEP);
         HIP_TRY(hipGetLastError());
     }
     g_kt = nullptr;
@@ -495,8 +463,7 @@ static int ensure_hit_buffers(pmap_result *res, uint32_t hit_cap) {
     if ((rc = res->h_read.ensure(hb)) || (rc = res->h_key.ensure(hb)) || (rc = res->h_pos.ensure(hb)) ||
         (rc = res->h_rank.ensure(hb)) || (rc = res->h_rec.ensure(hb)) || (rc = res->s_read.ensure(hb)) ||
         (rc = res->s_key.ensure(hb)) || (rc = res->s_pos.ensure(hb)) || (rc = res->s_rank.ensure(hb)) ||
-        (rc = res->s_rec.ensure(hb)) || (rc = res->cflags.ensure(hb / 32 + 64)) ||
-        (rc = res->coffs.ensure(hb / 32 + 64)))
+        (rc = res->s_rec.ensure(hb)))
         return rc;
     res->hit_cap = hit_cap;
     return PMAP_OK;
@@ -505,11 +472,7 @@ static int ensure_hit_buffers(pmap_result *res, uint32_t hit_cap) {
 static int ensure_cluster_buffers(pmap_result *res, uint32_t cl_cap) {
     int rc;
     const size_t cb = sizeof(uint32_t) * ((size_t) cl_cap + 1);
-    if ((rc = res->cstart.ensure(cb)) || (rc = res->c_size.ensure(cb)) || (rc = res->c_read.ensure(cb)) ||
-        (rc = res->c_key.ensure(cb)) || (rc = res->c_first.ensure(cb)) || (rc = res->c_last.ensure(cb)) ||
-        (rc = res->c_rank.ensure(cb)) || (rc = res->kflags.ensure(cb / 32 + 64)) ||
-        (rc = res->koffs.ensure(cb / 32 + 64)) || (rc = res->kidx.ensure(cb)) || (rc = res->k_rows.ensure(cb * 8)))
-        return rc;
+    if ((rc = res->cstart.ensure(cb)) || (rc = res->k_rows.ensure(cb * 8))) return rc;
     res->cl_cap = cl_cap;
     return PMAP_OK;
 }
@@ -548,11 +511,9 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
 
     // buffers whose size follows from the batch alone
     const uint32_t n_tiles = res->n_tiles;
-    const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS, n_groups = ((size_t) n_tiles + 63) / 64;
-    if ((rc = res->counters.ensure(sizeof(Counters))) || (rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) ||
-        (rc = res->group_sum.ensure(sizeof(uint4) * (n_groups + 1))) ||
-        (rc = res->group_hoff.ensure(sizeof(uint32_t) * (n_groups + 1))) || (rc = res->ents.ensure(4 * sb)) || (rc = res->hstart.ensure(sizeof(uint32_t) * (rd->n_reads + 1))) ||
-        (rc = res->hend.ensure(sizeof(uint32_t) * (rd->n_reads + 1))))
+    const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS;
+    if ((rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) || (rc = res->ents.ensure(4 * sb)) ||
+        (rc = res->hbounds.ensure(sizeof(uint32_t) * 2 * ((size_t) rd->n_reads + 1))))
         return rc;
     if (!fused && (rc = res->mkmer.ensure(2 * sb))) return rc;
 
@@ -573,22 +534,29 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         res->thr_exp = prm->expected_kmers;
     }
     // capacities of the data-dependent buffers: carried over from earlier calls, grown on overflow
-    if (res->hit_cap == 0 && (rc = ensure_hit_buffers(res, round_up(std::max<uint64_t>(n_tiles * 4ull, 4096), 256))))
+    if (res->hit_cap == 0 && (rc = ensure_hit_buffers(res, round_up(std::max<uint64_t>(n_tiles * 8ull, 4096), CUT_BLOCK))))
         return rc;
     if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), 256))))
         return rc;
 
     Counters hc;
+    unsigned long long n_mini = 0, n_hits = 0;
     KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
     memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
     for (int attempt = 0;; ++attempt) {
         kt.recorded = 0;
         memset(&hc, 0, sizeof(hc));
         if ((rc = run_pipeline(idx, rd, prm, res, fused, last, kt, &hc))) return rc;
-        if (hc.n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
+        if (hc.fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
+        n_mini = n_hits = 0;
+        for (int i = 0; i < TOTAL_LANES; ++i) {
+            n_mini += hc.totals[0][i];
+            n_hits += hc.totals[2][i];
+        }
+        if (n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
         bool again = false;
-        if (last >= PMAP_STAGE_HITS && hc.n_hits > res->hit_cap) {
-            if ((rc = ensure_hit_buffers(res, round_up(hc.n_hits + hc.n_hits / 8, 256)))) return rc;
+        if (last >= PMAP_STAGE_HITS && n_hits > res->hit_cap) {
+            if ((rc = ensure_hit_buffers(res, round_up(n_hits + n_hits / 8, CUT_BLOCK)))) return rc;
             again = true;
         }
         // at most one cluster per hit; when the hits overflowed the cluster count is only a lower bound
@@ -600,8 +568,8 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         if (!again) break;
         if (attempt > 6) return pmap_fail(PMAP_EHIP, "buffer sizing did not converge");
     }
-    cn.n_minimizers = hc.n_mini;
-    cn.n_hits = last >= PMAP_STAGE_HITS ? hc.n_hits : 0;
+    cn.n_minimizers = n_mini;
+    cn.n_hits = last >= PMAP_STAGE_HITS ? n_hits : 0;
     cn.n_clusters_all = last >= PMAP_STAGE_CLUSTER ? hc.n_cl : 0;
     cn.n_clusters = last >= PMAP_STAGE_CLUSTER ? hc.n_kept : 0;
     res->have_minimizers = !fused;
@@ -614,10 +582,9 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         // stage times = sums of their kernels; ms[4] = first kernel start to last kernel stop
         const float *km = res->kernel_ms;
         cn.ms[0] = km[KT_SKETCH];
-        cn.ms[1] = km[KT_PROBE] + km[KT_TILE_SCAN] + km[KT_SCATTER] + km[KT_SEG_BOUNDS];
+        cn.ms[1] = km[KT_PROBE] + km[KT_SCATTER];
         cn.ms[2] = km[KT_SORT];
-        cn.ms[3] = km[KT_CLUSTER_FLAGS] + km[KT_CLUSTER_SCAN] + km[KT_CLUSTER_STARTS] + km[KT_CLUSTER_TABLE] +
-                   km[KT_KEPT_SCAN] + km[KT_KEPT_GATHER];
+        cn.ms[3] = km[KT_CLUSTER_CUT] + km[KT_CLUSTER_KEEP];
         int lastk = -1;
         for (int i = 0; i < KT_COUNT; ++i)
             if (kt.recorded >> i & 1u) lastk = i;

@@ -43,67 +43,56 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
     if (lane == 0) ((uint32_t *) (tile_cnt + g))[2] = mine;
 }
 
-// Tiles are handled in groups of 64 (one wavefront of the scatter kernel per group).
-// group_sum[G] = sums of the tile counters over group G: one wavefront per group.
-__global__ __launch_bounds__(256) void group_reduce_kernel(const uint4 *__restrict__ tile_cnt, uint32_t n_tiles,
-                                                           uint4 *__restrict__ group_sum) {
-    const uint32_t lane = threadIdx.x & 63, G = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t t0 = G * 64;
-    if (t0 >= n_tiles) return;
-    const uint32_t t = t0 + lane;
-    uint4 c = make_uint4(0, 0, 0, 0);
-    if (t < n_tiles) c = tile_cnt[t];
-    const uint32_t x = wave_sum(c.x), y = wave_sum(c.y), z = wave_sum(c.z);
-    if (lane == 0) group_sum[G] = make_uint4(x, y, z, 0);
-}
-
-// one block: group_hoff = exclusive scan of the groups' hit counts; the three grand totals go to
-// the counters (minimizers, entries, hits)
-__global__ __launch_bounds__(256) void group_spine_kernel(const uint4 *__restrict__ group_sum, uint32_t n_groups,
-                                                          uint32_t *__restrict__ group_hoff,
-                                                          unsigned long long *__restrict__ n_mini,
-                                                          unsigned long long *__restrict__ n_ent,
-                                                          unsigned long long *__restrict__ n_hits) {
-    __shared__ uint32_t lds4[4];
-    unsigned long long cx = 0, cy = 0, cz = 0;
-    for (uint32_t base = 0; base < n_groups; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i < n_groups) v = group_sum[i];
-        uint32_t tx, ty, tz;
-        block_scan_256(v.x, lds4, &tx);
-        block_scan_256(v.y, lds4, &ty);
-        const uint32_t ex = block_scan_256(v.z, lds4, &tz);
-        if (i < n_groups) group_hoff[i] = (uint32_t) (cz + ex);
-        cx += tx;
-        cy += ty;
-        cz += tz;
-    }
-    if (threadIdx.x == 0) {
-        *n_mini = cx;
-        *n_ent = cy;
-        *n_hits = cz;
-    }
-}
-
-// scatter: one wavefront per group of 64 tiles.  The group's entries are numbered consecutively
-// (tile by tile, so still in (read, position) order); lane e takes entry e, finds its tile by a
-// search over the per-tile prefix sums held in the lanes, and writes the entry's hits (MinimizerHit
-// ctor, src/minihit.cpp:14-22) at the group's offset + the prefix sum of the record counts.
+// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A block takes 256 tiles, a wavefront
+// 64 of them.  The block's first hit is the chained prefix sum of the blocks'
+// hit counts; batch totals are added to the counters.  A wavefront numbers its entries
+// consecutively (tile by tile, so still in (read, position) order); lane e takes entry e, finds
+// its tile by a search over the per-tile prefix sums held in the lanes, and writes the entry's
+// hits at the running offset + the prefix sum of the record counts.
+// hbounds[r] = first hit of read r, hbounds[n_reads + r] = ~(one past its last hit); both start as
+// all-ones and are lowered with atomic minima where the read index changes between consecutive
+// entries and at the first and last entry of every wavefront.
+// emit = 0: totals only.
 __global__ __launch_bounds__(256) void scatter_group_kernel(
-    const uint4 *__restrict__ tile_cnt, const uint32_t *__restrict__ group_hoff, uint32_t n_tiles,
-    const uint4 *__restrict__ ents, const PmapRec *__restrict__ recs, uint32_t hit_cap,
+    const uint4 *__restrict__ tile_cnt, uint32_t n_tiles, const uint4 *__restrict__ ents,
+    const PmapRec *__restrict__ recs, uint32_t hit_cap, uint32_t emit, Counters *__restrict__ dc,
+    unsigned long long *__restrict__ gran, uint32_t n_reads, uint32_t *__restrict__ hbounds,
     uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key, uint32_t *__restrict__ h_pos,
     uint32_t *__restrict__ h_rank, uint32_t *__restrict__ h_rec) {
-    const uint32_t lane = threadIdx.x & 63, G = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t t0 = G * 64;
-    if (t0 >= n_tiles) return;
-    const uint32_t t = t0 + lane;
-    const uint32_t n = t < n_tiles ? tile_cnt[t].y : 0;
+    __shared__ uint32_t s_w[4][3];
+    __shared__ uint32_t s_scan[2];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t t0 = (b * 4 + wv) * 64, t = t0 + lane;
+    uint4 c = make_uint4(0, 0, 0, 0);
+    if (t < n_tiles) c = tile_cnt[t];
+    const uint32_t n = c.y;
     uint32_t E;
     const uint32_t estart = wave_scan(n, &E);
+    const uint32_t wmini = wave_sum(c.x), whits = wave_sum(c.z);
+    if (lane == 0) { s_w[wv][0] = wmini; s_w[wv][1] = E; s_w[wv][2] = whits; }
+    __syncthreads();
+    uint32_t bm = 0, be = 0, bh = 0, before = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        bm += s_w[i][0];
+        be += s_w[i][1];
+        bh += s_w[i][2];
+        if (i < wv) before += s_w[i][2];
+    }
+    if (threadIdx.x < 3) {
+        // spread over 64 words per total: atomics on one word would serialise the blocks
+        const uint32_t v = threadIdx.x == 0 ? bm : threadIdx.x == 1 ? be : bh;
+        if (v) atomicAdd(&dc->totals[threadIdx.x][b % TOTAL_LANES], (unsigned long long) v);
+    }
+    if (!emit) return;
+    const uint32_t excl = chained_scan(gran, b, bh, &dc->fail, s_scan);
+    if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_hits = (unsigned long long) excl + bh;
+    uint32_t run = excl + before;
     if (E == 0) return;
-    uint32_t run = group_hoff[G];
+    uint32_t *nhend = hbounds + n_reads;
+    bool have_prev = false;
+    uint32_t prev_r = 0, prev_end = 0;
     for (uint32_t base = 0; base < E; base += 64) {
         const uint32_t e = base + lane;
         // the tile of entry e: the largest T with estart[T] <= e
@@ -117,11 +106,11 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
         const uint32_t first = __shfl(estart, T);
         uint4 ent = make_uint4(0, 0, 0, 0);
         if (e < E) ent = ents[(uint64_t) (t0 + T) * WAVE_POS + (e - first)];
-        const uint32_t c = ent.w;
+        const uint32_t cn = ent.w;
         uint32_t tot;
-        const uint32_t ho = run + wave_scan(c, &tot);
+        const uint32_t ho = run + wave_scan(cn, &tot);
         const uint32_t pos = ent.y & 0x7FFFFFFFu, strand = ent.y >> 31;
-        for (uint32_t q = 0; q < c; ++q) {
+        for (uint32_t q = 0; q < cn; ++q) {
             const uint32_t d = ho + q;
             if (d >= hit_cap) break;
             const uint4 rec = *(const uint4 *) (recs + ent.z + q);   // prg, knode<<1|strand, rank, orig
@@ -132,8 +121,27 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
             h_rank[d] = rec.z;
             h_rec[d] = rec.w;
         }
+        // segment bounds: the entry with hits before this one ends where this one starts
+        const unsigned long long act = __ballot(cn != 0);
+        if (act) {
+            const unsigned long long lower = act & ((1ull << lane) - 1ull);
+            const int P = lower ? 63 - __clzll((long long) lower) : 0;
+            const uint32_t rp_lane = __shfl(ent.x, P);
+            if (cn != 0) {
+                const bool has = lower != 0 || have_prev;
+                const uint32_t rp = lower ? rp_lane : prev_r;
+                const uint32_t at = ho < hit_cap ? ho : hit_cap;
+                if (!has || rp != ent.x) atomicMin(&hbounds[ent.x], at);
+                if (has && rp != ent.x) atomicMin(&nhend[rp], ~at);
+            }
+            const int last = 63 - __clzll((long long) act);
+            prev_r = __shfl(ent.x, last);
+            prev_end = __shfl(ho + cn, last);
+            have_prev = true;
+        }
         run += tot;
     }
+    if (have_prev && lane == 0) atomicMin(&nhend[prev_r], ~(prev_end < hit_cap ? prev_end : hit_cap));
 }
 
 // one field (0 minimizers, 1 entries, 2 hits) of the tile counters as a plain array

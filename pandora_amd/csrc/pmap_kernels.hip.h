@@ -196,28 +196,84 @@ __global__ __launch_bounds__(256) void read_meta_kernel(const uint32_t *__restri
 
 #include "pmap_sketch.hip.h"
 
+// ---------------------------------------------------------------------------
+// Chained prefix sum over the blocks of one launch.  Block b = blockIdx.x adds `total` and gets
+// back the sum of the totals of blocks 0..b-1.  Workgroups are dispatched in index order on every
+// XCD, so the lowest-numbered unfinished block is always resident and never waits: the chain
+// cannot stall itself, and a block publishes its own total before it looks back.  gran[b] is one 8-byte word
+// {state << 32 | value}: state 1 = value is the block's own total, 2 = value is the inclusive
+// prefix up to and including the block; the word is written and read whole with agent-scope
+// atomics, so the value never needs a separate flag or fence.  gran must be zero before the launch.
+// The wait is bounded and reports through *fail (no hang if the dispatch order ever differs).
+// Called by every thread of the block; lds2 = two words of LDS.
+static const uint32_t CHAIN_SPIN_LIMIT = 1u << 18;
+static const int CHAIN_SLABS = 8;     // one look-back round reads 8 x 64 predecessors, all loads in flight together
+
+__device__ __forceinline__ uint32_t chained_scan(unsigned long long *gran, uint32_t b, uint32_t total,
+                                                 uint32_t *fail, uint32_t *lds2) {
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        uint32_t excl = 0;
+        if (b != 0) {
+            if (lane == 0)
+                __hip_atomic_store(gran + b, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t top = (int64_t) b - 1;          // nearest predecessor not yet added
+            for (;;) {
+                // slab i, lane l looks at block top - (64 i + l): nearest first
+                unsigned long long g[CHAIN_SLABS];
+                uint32_t spins = 0;
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int i = 0; i < CHAIN_SLABS; ++i) {
+                        const int64_t j = top - (int64_t) (64 * i + lane);
+                        g[i] = 2ull << 32;          // before block 0: an inclusive prefix of 0
+                        if (j >= 0) g[i] = __hip_atomic_load(gran + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && (g[i] >> 32) != 0;
+                    }
+                    if (__all(ready)) break;
+                    if (++spins > CHAIN_SPIN_LIMIT) {           // uniform: every lane counts alike
+                        if (lane == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int i = 0; i < CHAIN_SLABS; ++i)
+                            if ((g[i] >> 32) == 0) g[i] = 2ull << 32;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                bool done = false;
+#pragma unroll
+                for (int i = 0; i < CHAIN_SLABS; ++i) {
+                    if (!done) {
+                        const unsigned long long incl = __ballot((g[i] >> 32) == 2);
+                        if (incl) {
+                            const uint32_t stop = (uint32_t) __builtin_ctzll(incl);   // nearest block that knows its prefix
+                            excl += wave_sum(lane <= stop ? (uint32_t) g[i] : 0u);
+                            done = true;
+                        } else {
+                            excl += wave_sum((uint32_t) g[i]);
+                        }
+                    }
+                }
+                if (done) break;
+                top -= 64 * CHAIN_SLABS;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(gran + b, (2ull << 32) | (uint32_t) (excl + total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            lds2[0] = excl;
+        }
+    }
+    __syncthreads();
+    return lds2[0];
+}
+
 #include "pmap_emit.hip.h"
 
 __device__ __forceinline__ uint32_t clamp_count(const unsigned long long *p, uint32_t cap) {
     const unsigned long long v = *p;
     return v < cap ? (uint32_t) v : cap;
-}
-
-// first / one-past-last hit of every read that has hits
-__global__ __launch_bounds__(256) void seg_bounds_kernel(const uint32_t *__restrict__ h_read,
-                                                         const unsigned long long *__restrict__ n_hits_p,
-                                                         uint32_t hit_cap, uint32_t *__restrict__ hstart,
-                                                         uint32_t *__restrict__ hend) {
-    const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_hits) return;
-    const uint32_t r = h_read[i];
-    if (i == 0) hstart[r] = 0;
-    else {
-        const uint32_t rp = h_read[i - 1];
-        if (rp != r) { hstart[r] = i; hend[rp] = i; }
-    }
-    if (i == n_hits - 1) hend[r] = n_hits;
 }
 
 // ---------------------------------------------------------------------------
@@ -232,8 +288,7 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
                                                         const uint32_t *__restrict__ h_pos,
                                                         const uint32_t *__restrict__ h_rank,
                                                         const uint32_t *__restrict__ h_rec,
-                                                        const uint32_t *__restrict__ hstart,
-                                                        const uint32_t *__restrict__ hend,
+                                                        const uint32_t *__restrict__ hbounds, uint32_t n_reads,
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
                                                         uint32_t *__restrict__ s_rec) {
@@ -247,8 +302,8 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
     if (active) {
         r = h_read[i];
         key = h_key[i];
-        s = hstart[r];
-        e = hend[r];
+        s = hbounds[r];
+        e = ~hbounds[n_reads + r];
     }
     if (threadIdx.x == 0) range[0] = s;
     if (active && (threadIdx.x == 255 || i == n_hits - 1)) range[1] = e;
@@ -278,94 +333,102 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
 }
 
 // ---------------------------------------------------------------------------
-// cluster cut (src/utils.cpp:206-209): one flag bit per sorted hit that starts a cluster; bits beyond
-// the last hit are written as zero so that the flag array can be scanned over its whole capacity
-__global__ __launch_bounds__(256) void cluster_flags_kernel(const unsigned long long *__restrict__ n_hits_p,
-                                                            uint32_t hit_cap, const uint32_t *__restrict__ s_read,
-                                                            const uint32_t *__restrict__ s_key,
-                                                            const uint32_t *__restrict__ s_pos, int max_diff,
-                                                            unsigned long long *__restrict__ cflags64) {
-    const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    bool f = false;
-    if (i < n_hits) {
-        if (i == 0) f = true;
-        else {
-            const int d = (int) s_pos[i] - (int) s_pos[i - 1];
-            f = s_read[i] != s_read[i - 1] || s_key[i] != s_key[i - 1] || (d < 0 ? -d : d) > max_diff;
+// cluster cut (src/utils.cpp:206-209).  A block takes 2048 sorted hits (8 rounds of
+// 256), flags the hits that start a cluster, and writes their indices to cstart at the chained
+// prefix sum of the blocks' flag counts.  The last block writes the cluster total.
+static const uint32_t CUT_ROUNDS = 8, CUT_BLOCK = 256 * CUT_ROUNDS;
+
+__global__ __launch_bounds__(256) void cluster_cut_kernel(Counters *__restrict__ dc, uint32_t hit_cap,
+                                                          const uint32_t *__restrict__ s_read,
+                                                          const uint32_t *__restrict__ s_key,
+                                                          const uint32_t *__restrict__ s_pos, int max_diff,
+                                                          unsigned long long *__restrict__ gran, uint32_t cl_cap,
+                                                          uint32_t *__restrict__ cstart) {
+    __shared__ uint32_t s_cnt[CUT_ROUNDS * 4], s_scan[2];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
+    uint32_t fbits = 0, rank[CUT_ROUNDS];
+#pragma unroll
+    for (uint32_t r = 0; r < CUT_ROUNDS; ++r) {
+        const uint32_t i = b * CUT_BLOCK + r * 256 + threadIdx.x;
+        bool f = false;
+        if (i < n_hits) {
+            if (i == 0) f = true;
+            else {
+                const int d = (int) s_pos[i] - (int) s_pos[i - 1];
+                f = s_read[i] != s_read[i - 1] || s_key[i] != s_key[i - 1] || (d < 0 ? -d : d) > max_diff;
+            }
+        }
+        const unsigned long long m = __ballot(f);
+        rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
+        if (f) fbits |= 1u << r;
+        if (lane == 0) s_cnt[r * 4 + wv] = (uint32_t) __popcll(m);
+    }
+    __syncthreads();
+    // exclusive scan of the 32 (round, wavefront) counts, in hit order
+    uint32_t total = 0, mine[CUT_ROUNDS];
+#pragma unroll
+    for (uint32_t r = 0; r < CUT_ROUNDS; ++r) {
+#pragma unroll
+        for (uint32_t v = 0; v < 4; ++v) {
+            if (v == wv) mine[r] = total;
+            total += s_cnt[r * 4 + v];
         }
     }
-    unsigned long long b = __ballot(f);
-    if ((threadIdx.x & 63) == 0) cflags64[i >> 6] = b;
+    const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);
+#pragma unroll
+    for (uint32_t r = 0; r < CUT_ROUNDS; ++r)
+        if (fbits >> r & 1u) {
+            const uint32_t c = excl + mine[r] + rank[r];
+            if (c < cl_cap) cstart[c] = b * CUT_BLOCK + r * 256 + threadIdx.x;
+        }
+    if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_cl = (unsigned long long) excl + total;
 }
 
-// positions of the set bits of a flag array, in order (offs = exclusive scan of the popcounts)
-__global__ __launch_bounds__(256) void bit_positions_kernel(const uint32_t *__restrict__ flags,
-                                                            const uint32_t *__restrict__ offs, uint32_t n_fw,
-                                                            uint32_t out_cap, uint32_t *__restrict__ out) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_fw) return;
-    uint32_t bits = flags[g];
-    uint32_t o = offs[g];
-    while (bits) {
-        const uint32_t b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        if (o < out_cap) out[o] = g * 32 + b;
-        ++o;
-    }
-}
-
-// one thread per cluster: summary row + "kept" flag (size > threshold, src/utils.cpp:211-220)
-__global__ __launch_bounds__(256) void cluster_table_kernel(const unsigned long long *__restrict__ n_cl_p,
-                                                            uint32_t cl_cap,
-                                                            const unsigned long long *__restrict__ n_hits_p,
-                                                            uint32_t hit_cap, const uint32_t *__restrict__ cstart,
-                                                            const uint32_t *__restrict__ s_read,
-                                                            const uint32_t *__restrict__ s_key,
-                                                            const uint32_t *__restrict__ s_pos,
-                                                            const uint32_t *__restrict__ s_rank,
-                                                            const uint32_t *__restrict__ thr,
-                                                            uint32_t *__restrict__ c_size, uint32_t *__restrict__ c_read,
-                                                            uint32_t *__restrict__ c_key, uint32_t *__restrict__ c_first,
-                                                            uint32_t *__restrict__ c_last, uint32_t *__restrict__ c_rank,
-                                                            unsigned long long *__restrict__ kflags64) {
-    const uint32_t n_cl = clamp_count(n_cl_p, cl_cap), n_hits = clamp_count(n_hits_p, hit_cap);
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+// One thread per cluster, blocks of 256: size threshold (src/utils.cpp:211-220)
+// and, for the clusters kept, the summary row {first hit, size, read, prg << 1 | !forward, first
+// position, last position, path rank of the first hit, cluster number} at the chained prefix sum
+// of the kept counts.  The last block writes the kept total.
+__global__ __launch_bounds__(256) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
+                                                           uint32_t hit_cap, const uint32_t *__restrict__ cstart,
+                                                           const uint32_t *__restrict__ s_read,
+                                                           const uint32_t *__restrict__ s_key,
+                                                           const uint32_t *__restrict__ s_pos,
+                                                           const uint32_t *__restrict__ s_rank,
+                                                           const uint32_t *__restrict__ thr,
+                                                           unsigned long long *__restrict__ gran,
+                                                           uint32_t *__restrict__ k_rows) {
+    __shared__ uint32_t s_cnt[4], s_scan[2];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n_cl = clamp_count(&dc->n_cl, cl_cap), n_hits = clamp_count(&dc->n_hits, hit_cap);
+    const uint32_t c = b * 256 + threadIdx.x;
     bool kept = false;
+    uint32_t s = 0, e = 0, key = 0;
     if (c < n_cl) {
-        const uint32_t s = cstart[c];
-        const uint32_t e = c + 1 < n_cl ? cstart[c + 1] : n_hits;
-        const uint32_t size = e - s, key = s_key[s];
-        c_size[c] = size;
-        c_read[c] = s_read[s];
-        c_key[c] = key;
-        c_first[c] = s_pos[s];
-        c_last[c] = s_pos[e - 1];
-        c_rank[c] = s_rank[s];
-        kept = size > thr[key >> 1];
+        s = cstart[c];
+        e = c + 1 < n_cl ? cstart[c + 1] : n_hits;
+        key = s_key[s];
+        kept = e - s > thr[key >> 1];
     }
-    unsigned long long b = __ballot(kept);
-    if ((threadIdx.x & 63) == 0) kflags64[c >> 6] = b;
-}
-
-// gathers the rows of the kept clusters
-__global__ __launch_bounds__(256) void cluster_gather_kernel(const unsigned long long *__restrict__ n_kept_p,
-                                                             uint32_t cl_cap, const uint32_t *__restrict__ kidx,
-                                                             const uint32_t *__restrict__ cstart,
-                                                             const uint32_t *__restrict__ c_size,
-                                                             const uint32_t *__restrict__ c_read,
-                                                             const uint32_t *__restrict__ c_key,
-                                                             const uint32_t *__restrict__ c_first,
-                                                             const uint32_t *__restrict__ c_last,
-                                                             const uint32_t *__restrict__ c_rank,
-                                                             uint32_t *__restrict__ k_rows) {
-    const uint32_t n_kept = clamp_count(n_kept_p, cl_cap);
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_kept) return;
-    const uint32_t c = kidx[t];
-    uint32_t *row = k_rows + (uint64_t) t * 8;
-    *(uint4 *) row = make_uint4(cstart[c], c_size[c], c_read[c], c_key[c]);
-    *(uint4 *) (row + 4) = make_uint4(c_first[c], c_last[c], c_rank[c], c);
+    const unsigned long long m = __ballot(kept);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
+    if (lane == 0) s_cnt[wv] = (uint32_t) __popcll(m);
+    __syncthreads();
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < 4; ++v) {
+        if (v == wv) before = total;
+        total += s_cnt[v];
+    }
+    const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);
+    if (kept) {
+        uint32_t *row = k_rows + (uint64_t) (excl + before + rank) * 8;
+        *(uint4 *) row = make_uint4(s, e - s, s_read[s], key);
+        *(uint4 *) (row + 4) = make_uint4(s_pos[s], s_pos[e - 1], s_rank[s], c);
+    }
+    if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_kept = (unsigned long long) excl + total;
 }
 
 #endif

@@ -25,14 +25,19 @@ struct Quad {
     HT v[4];
 };
 
+// 16-byte LDS read of quad q.  The empty asm marks every component as used: left alone, the
+// compiler narrows the read to the components a window shape needs, and dword reads at a 16-byte
+// lane stride hit 8 of the 32 banks (4-way conflicts), while the full ds_read_b128 is conflict-free.
 template <typename HT>
 __device__ __forceinline__ Quad<HT> ldq(const HT *a, int q) {
     Quad<HT> r;
     if (sizeof(HT) == 4) {
-        const uint4 x = *(const uint4 *) (a + 4 * q);
+        uint4 x = *(const uint4 *) (a + 4 * q);
+        asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
         r.v[0] = (HT) x.x; r.v[1] = (HT) x.y; r.v[2] = (HT) x.z; r.v[3] = (HT) x.w;
     } else {
-        const ulonglong2 x = *(const ulonglong2 *) (a + 4 * q), y = *(const ulonglong2 *) (a + 4 * q + 2);
+        ulonglong2 x = *(const ulonglong2 *) (a + 4 * q), y = *(const ulonglong2 *) (a + 4 * q + 2);
+        asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(y.x), "+v"(y.y));
         r.v[0] = (HT) x.x; r.v[1] = (HT) x.y; r.v[2] = (HT) y.x; r.v[3] = (HT) y.y;
     }
     return r;
