@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--workload", default="nanopore_1k")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=2, help="steps in flight (1 = blocking pmap_map)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all inside the timed steps; all kernel times come from the second pass")
     args = ap.parse_args()
@@ -117,13 +118,16 @@ def main():
     reads = api.Reads(bases, offsets)
     upload_s = time.perf_counter() - t0
 
-    def step(res, profile):
+    def step(res, profile, wait=True):
         return api.map_reads(gidx, reads, prm["w"], prm["k"], prm["max_diff"], fraction, prm["min_cluster_size"],
-                             expected, profile=profile, result=res)
+                             expected, profile=profile, result=res, wait=wait)
 
-    res = None
-    for _ in range(args.warmup):
-        res = step(res, 0)
+    # `depth` result objects take turns, so that the host enqueues a step while the GPU runs the one before
+    # (pmap_map_async / pmap_map_wait); depth 1 is the blocking pmap_map
+    depth = max(1, args.depth)
+    ring = [None] * depth
+    for i in range(max(args.warmup, depth)):
+        ring[i % depth] = step(ring[i % depth], 0)
 
     def sync():
         torch.cuda.synchronize()
@@ -134,14 +138,29 @@ def main():
     sync()
     t0 = time.perf_counter()
     prof = 0 if args.no_kernel_events else 2
-    for _ in range(args.steps):
+    inflight = [False] * depth
+
+    def retire(j):
+        nonlocal sketch_ms
+        ring[j].wait()
+        inflight[j] = False
+        if prof:
+            sketch_ms += ring[j].kernel_ms()["sketch"]
+
+    for i in range(args.steps):
         # profile=2: one pair of HIP events rides on the dispatch of the sketch kernel (the dominant one)
         # on the library's stream, inside the timed region
-        res = step(res, prof)
-        if prof:
-            sketch_ms += res.kernel_ms()["sketch"]
+        j = i % depth
+        if inflight[j]:
+            retire(j)
+        ring[j] = step(ring[j], prof, wait=False)
+        inflight[j] = True
+    for j in range(depth):
+        if inflight[j]:
+            retire(j)
     sync()
     elapsed = time.perf_counter() - t0
+    res = ring[(args.steps - 1) % depth] if args.steps else ring[0]
     cn = res.counts()
     # second, untimed pass with events on every kernel, for the per-phase table
     for _ in range(args.steps):
@@ -200,7 +219,8 @@ def main():
                        "minimizers_per_gpu": cn["n_minimizers"], "hits_per_gpu": cn["n_hits"],
                        "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],
                        "index_keys": int(len(si.keys)), "index_records": int(len(si.rec_prg)),
-                       "parallelism": "reads sharded over %d GPU(s), index replicated" % world},
+                       "parallelism": "reads sharded over %d GPU(s), index replicated" % world,
+                       "steps_in_flight": depth},
             "hits_per_s": total_hits * args.steps / elapsed,
             "roofline": roofline,
             "phases": phases,

@@ -148,6 +148,17 @@ float pmap_fraction(float e_rate, uint32_t k);
 int pmap_map(const pmap_index_t *idx, const pmap_reads_t *reads, const pmap_params_t *prm,
              pmap_result_t **result);
 
+/* The same in two halves, so that the host can prepare and enqueue the next batch
+ * while the GPU maps this one (no counterpart in the reference, which is
+ * synchronous and single-threaded).  pmap_map_async enqueues the kernels and
+ * returns; pmap_map_wait blocks until they are done, maps the batch again if a
+ * result buffer turned out too small, and makes the result readable.  idx and
+ * reads must stay alive until the wait; every pmap_result_* accessor waits by
+ * itself.  Results in flight at the same time must be different objects. */
+int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *reads, const pmap_params_t *prm,
+                   pmap_result_t **result);
+int pmap_map_wait(pmap_result_t *result);
+
 #define PMAP_N_TIMERS 8
 typedef struct {
     uint32_t n_reads;

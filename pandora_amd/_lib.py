@@ -70,6 +70,8 @@ SIGNATURES = {
     "pmap_reads_destroy": (None, [C.c_void_p]),
     "pmap_fraction": (C.c_float, [C.c_float, C.c_uint32]),
     "pmap_map": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    "pmap_map_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    "pmap_map_wait": (C.c_int, [C.c_void_p]),
     "pmap_result_counts": (C.c_int, [C.c_void_p, C.POINTER(Counts)]),
     "pmap_result_kernel_ms": (C.c_int, [C.c_void_p, f32p]),
     "pmap_kernel_name": (C.c_char_p, [C.c_int]),

@@ -165,6 +165,12 @@ class MapResult:
 
     def __init__(self):
         self._h = C.c_void_p()
+        self._keep = None
+
+    def wait(self):
+        """Blocks until a map_reads(..., wait=False) has finished."""
+        _check(_lib.load().pmap_map_wait(self._h))
+        return self
 
     def counts(self):
         c = _lib.Counts()
@@ -229,12 +235,16 @@ class MapResult:
 
 
 def map_reads(index, reads, w, k, max_diff, fraction_required, min_cluster_size=10, expected_kmers=UINT32_MAX,
-              last_stage=0, profile=0, result=None, unfused=False):
-    """Seq::minimizer_sketch -> add_read_hits -> MinimizerHits::sort -> define_clusters on the GPU."""
+              last_stage=0, profile=0, result=None, unfused=False, wait=True):
+    """Seq::minimizer_sketch -> add_read_hits -> MinimizerHits::sort -> define_clusters on the GPU.
+    wait=False only enqueues the kernels (pmap_map_async): call result.wait(), or any accessor, later;
+    index and reads must stay alive until then."""
     res = result if result is not None else MapResult()
     prm = _lib.Params(w, k, max_diff, fraction_required, min_cluster_size, expected_kmers, last_stage, profile,
                       1 if unfused else 0)
-    _check(_lib.load().pmap_map(index._h, reads._h, C.byref(prm), C.byref(res._h)))
+    fn = _lib.load().pmap_map if wait else _lib.load().pmap_map_async
+    _check(fn(index._h, reads._h, C.byref(prm), C.byref(res._h)))
+    res._keep = (index, reads)
     return res
 
 

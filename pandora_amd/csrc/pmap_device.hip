@@ -139,7 +139,17 @@ struct pmap_result {
     float thr_fraction = 0;
     uint32_t thr_min = 0, thr_exp = 0;
     hipEvent_t kev[2 * PMAP_N_KERNELS];
+    hipEvent_t done = nullptr;        // after the counters of the last enqueued run have reached hc
     bool events = false;
+    // a run that was enqueued and not yet waited for
+    bool pending = false;
+    Counters *hc = nullptr;           // pinned host copy of the device counters
+    const pmap_index *p_idx = nullptr;
+    const pmap_reads *p_rd = nullptr;
+    pmap_params_t p_prm;
+    bool p_fused = false;
+    uint32_t p_last = 0;
+    uint32_t kt_recorded = 0;
     std::vector<DevBuf *> all() {
         return {&state, &tile_cnt, &bsum, &scratch_total, &mkmer, &ents, &h_read, &h_key, &h_pos, &h_rank, &h_rec,
                 &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &cstart, &k_rows, &thr};
@@ -328,8 +338,6 @@ static KTimer *g_kt = nullptr;
         else kernel<<<grid, dim3(256), 0, g_stream>>>(__VA_ARGS__);                                       \
     } while (0)
 
-// exclusive scan (of values or popcounts) of n uint32 into out; the total stays on the device.
-// out may be null (total only).
 void KTimer::events(hipEvent_t *s, hipEvent_t *e) {
     *s = *e = nullptr;
     if (!on || cur < 0) return;
@@ -337,6 +345,8 @@ void KTimer::events(hipEvent_t *s, hipEvent_t *e) {
     *e = res->kev[2 * cur + 1];
 }
 
+// exclusive scan (of values or popcounts) of n uint32 into out; the total stays on the device.
+// out may be null (total only).
 template <bool POPC>
 static int device_scan(pmap_result *res, const uint32_t *in, uint32_t *out, uint64_t n, unsigned long long *d_total) {
     if (n == 0) {
@@ -358,10 +368,16 @@ static int device_scan(pmap_result *res, const uint32_t *in, uint32_t *out, uint
 
 static uint32_t round_up(uint64_t v, uint32_t m) { return (uint32_t) ((v + m - 1) / m * m); }
 
-// launches the whole pipeline once with the current capacities; counters come back in *hc
-static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_params_t *prm, pmap_result *res,
-                        bool fused, uint32_t last, KTimer &kt, Counters *hc) {
+// enqueues the whole pipeline once with the current capacities; the counters arrive in res->hc
+// when res->done has happened
+static int run_pipeline(pmap_result *res) {
     int rc;
+    const pmap_index *idx = res->p_idx;
+    const pmap_reads *rd = res->p_rd;
+    const pmap_params_t *prm = &res->p_prm;
+    const bool fused = res->p_fused;
+    const uint32_t last = res->p_last;
+    KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
     const uint32_t k = prm->k, w = prm->w;
     const bool k32 = k <= 15;
     const uint32_t n_tiles = res->n_tiles;
@@ -375,7 +391,14 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
     Counters *dc = res->state.as<Counters>();
     unsigned long long *gran_s = (unsigned long long *) (dc + 1), *gran_a = gran_s + res->n_sblk,
                        *gran_b = gran_a + res->n_ablk;
-    HIP_TRY(hipMemsetAsync(dc, 0, state_bytes, g_stream));
+    if (n_tiles == 0) {           // empty batch: nothing to launch
+        memset(res->hc, 0, sizeof(Counters));
+        res->kt_recorded = 0;
+        HIP_TRY(hipEventRecord(res->done, g_stream));
+        return PMAP_OK;
+    }
+    // the sketch kernel clears the state block and the read bounds for the kernels after it
+    const uint32_t n_state_words = (uint32_t) (state_bytes / 8), n_hb = 2 * (rd->n_reads + 1);
     g_kt = &kt;
 
     // ---- sketch (+ probe when fused)
@@ -383,7 +406,8 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         kt.begin(KT_SKETCH);
 #define SKETCH_ARGS                                                                                                   \
     rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, idx->d_slots, idx->log2cap,            \
-        idx->d_filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>()
+        idx->d_filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>(), \
+        res->state.as<unsigned long long>(), n_state_words, res->hbounds.as<uint32_t>(), n_hb
 #define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
     KLAUNCH(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
         // w = 14 (the default of pandora map) and w = 1 (dense sketches) have their own instantiations
@@ -413,8 +437,6 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
                     idx->log2cap, idx->d_filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>());
             kt.end(KT_PROBE);
         }
-        if (emit)
-            HIP_TRY(hipMemsetAsync(res->hbounds.p, 0xFF, sizeof(uint32_t) * 2 * ((size_t) rd->n_reads + 1), g_stream));
         kt.begin(KT_SCATTER);
         KLAUNCH(scatter_group_kernel, dim3(res->n_sblk), res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
                 idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, gran_s, rd->n_reads + 1, res->hbounds.as<uint32_t>(),
@@ -452,8 +474,9 @@ static int run_pipeline(const pmap_index *idx, const pmap_reads *rd, const pmap_
         HIP_TRY(hipGetLastError());
     }
     g_kt = nullptr;
-    HIP_TRY(hipMemcpyAsync(hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    res->kt_recorded = kt.recorded;
+    HIP_TRY(hipMemcpyAsync(res->hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipEventRecord(res->done, g_stream));
     return PMAP_OK;
 }
 
@@ -477,8 +500,10 @@ static int ensure_cluster_buffers(pmap_result *res, uint32_t cl_cap) {
     return PMAP_OK;
 }
 
-extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const pmap_params_t *prm,
-                        pmap_result_t **result) {
+extern "C" int pmap_map_wait(pmap_result_t *res);
+
+extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, const pmap_params_t *prm,
+                              pmap_result_t **result) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!idx || !rd || !prm || !result) return pmap_fail(PMAP_EINVAL, "null argument");
@@ -492,9 +517,12 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         memset(&res->counts, 0, sizeof(res->counts));
         memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
         for (auto &e : res->kev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&res->done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **) &res->hc, sizeof(Counters), hipHostMallocDefault));
         res->events = true;
         *result = res;
     }
+    if (res->pending && (rc = pmap_map_wait(res))) return rc;   // the buffers are about to be reused
     const uint32_t last = prm->last_stage ? prm->last_stage : PMAP_STAGE_CLUSTER;
     const bool fused = !(prm->flags & PMAP_FLAG_UNFUSED) && last >= PMAP_STAGE_HITS;
     pmap_counts_t &cn = res->counts;
@@ -528,6 +556,7 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         if ((rc = res->thr.ensure(sizeof(uint32_t) * res->thr_host.size()))) return rc;
         HIP_TRY(hipMemcpyAsync(res->thr.p, res->thr_host.data(), sizeof(uint32_t) * res->thr_host.size(),
                                hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));   // thr_host is pageable and may change before the copy ran
         res->thr_idx = idx;
         res->thr_fraction = prm->fraction;
         res->thr_min = prm->min_cluster_size;
@@ -539,14 +568,27 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
     if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), 256))))
         return rc;
 
-    Counters hc;
+    res->p_idx = idx;
+    res->p_rd = rd;
+    res->p_prm = *prm;
+    res->p_fused = fused;
+    res->p_last = last;
+    if ((rc = run_pipeline(res))) return rc;
+    res->pending = true;
+    return PMAP_OK;
+}
+
+extern "C" int pmap_map_wait(pmap_result_t *res) {
+    if (!res) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (!res->pending) return PMAP_OK;
+    res->pending = false;
+    int rc;
+    const uint32_t last = res->p_last;
+    pmap_counts_t &cn = res->counts;
     unsigned long long n_mini = 0, n_hits = 0;
-    KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
-    memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
     for (int attempt = 0;; ++attempt) {
-        kt.recorded = 0;
-        memset(&hc, 0, sizeof(hc));
-        if ((rc = run_pipeline(idx, rd, prm, res, fused, last, kt, &hc))) return rc;
+        HIP_TRY(hipEventSynchronize(res->done));
+        const Counters &hc = *res->hc;
         if (hc.fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
         n_mini = n_hits = 0;
         for (int i = 0; i < TOTAL_LANES; ++i) {
@@ -567,16 +609,20 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         }
         if (!again) break;
         if (attempt > 6) return pmap_fail(PMAP_EHIP, "buffer sizing did not converge");
+        // a buffer was too small: it has been grown (freeing waits for the device), map the batch again
+        if ((rc = run_pipeline(res))) return rc;
     }
+    const Counters &hc = *res->hc;
     cn.n_minimizers = n_mini;
     cn.n_hits = last >= PMAP_STAGE_HITS ? n_hits : 0;
     cn.n_clusters_all = last >= PMAP_STAGE_CLUSTER ? hc.n_cl : 0;
     cn.n_clusters = last >= PMAP_STAGE_CLUSTER ? hc.n_kept : 0;
-    res->have_minimizers = !fused;
-    if (kt.on) {
+    res->have_minimizers = !res->p_fused;
+    if (res->p_prm.profile >= 1) {
+        const uint32_t recorded = res->kt_recorded;
         for (int i = 0; i < KT_COUNT; ++i) {
             float ms = 0;
-            if ((kt.recorded >> i & 1u) && hipEventElapsedTime(&ms, res->kev[2 * i], res->kev[2 * i + 1]) == hipSuccess)
+            if ((recorded >> i & 1u) && hipEventElapsedTime(&ms, res->kev[2 * i], res->kev[2 * i + 1]) == hipSuccess)
                 res->kernel_ms[i] = ms;
         }
         // stage times = sums of their kernels; ms[4] = first kernel start to last kernel stop
@@ -587,21 +633,36 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
         cn.ms[3] = km[KT_CLUSTER_CUT] + km[KT_CLUSTER_KEEP];
         int lastk = -1;
         for (int i = 0; i < KT_COUNT; ++i)
-            if (kt.recorded >> i & 1u) lastk = i;
-        if ((kt.recorded & 1u) && lastk >= 0)
+            if (recorded >> i & 1u) lastk = i;
+        if ((recorded & 1u) && lastk >= 0)
             (void) hipEventElapsedTime(&cn.ms[4], res->kev[0], res->kev[2 * lastk + 1]);
     }
     return PMAP_OK;
 }
 
+extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const pmap_params_t *prm,
+                        pmap_result_t **result) {
+    int rc = pmap_map_async(idx, rd, prm, result);
+    if (rc) return rc;
+    return pmap_map_wait(*result);
+}
+
+// every accessor of a result first waits for a run that is still in flight
+static int settled(const pmap_result_t *res) {
+    if (!res) return pmap_fail(PMAP_EINVAL, "null argument");
+    return res->pending ? pmap_map_wait(const_cast<pmap_result_t *>(res)) : PMAP_OK;
+}
+
 extern "C" int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out) {
     if (!res || !out) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc = settled(res)) return rc;
     *out = res->counts;
     return PMAP_OK;
 }
 
 extern "C" int pmap_result_kernel_ms(const pmap_result_t *res, float *ms) {
     if (!res || !ms) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc = settled(res)) return rc;
     memcpy(ms, res->kernel_ms, sizeof(res->kernel_ms));
     return PMAP_OK;
 }
@@ -621,6 +682,7 @@ static int fetch(const void *dev, size_t n, std::vector<T> *out) {
 extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer, uint32_t *read_id, uint32_t *pos,
                                       uint8_t *strand) {
     if (!cres) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc0 = settled(cres)) return rc0;
     pmap_result *res = const_cast<pmap_result *>(cres);
     if (!res->have_minimizers)
         return pmap_fail(PMAP_EINVAL, "the complete minimizer list was not kept: map with PMAP_FLAG_UNFUSED or last_stage = PMAP_STAGE_SKETCH");
@@ -668,6 +730,7 @@ extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer,
 extern "C" int pmap_result_hits(const pmap_result_t *res, int sorted, uint32_t *read_id, uint32_t *pos,
                                 uint32_t *prg_id, uint32_t *rec, uint8_t *is_forward) {
     if (!res) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc0 = settled(res)) return rc0;
     const size_t n = res->counts.n_hits;
     if (n == 0) return PMAP_OK;
     int rc;
@@ -692,6 +755,7 @@ extern "C" int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, u
                                     uint32_t *prg_id, uint8_t *is_forward, uint32_t *first_pos, uint32_t *last_pos,
                                     uint32_t *first_rank) {
     if (!res) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc0 = settled(res)) return rc0;
     const size_t n = res->counts.n_clusters;
     std::vector<uint32_t> rows;
     int rc;
@@ -712,9 +776,12 @@ extern "C" int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, u
 
 extern "C" void pmap_result_destroy(pmap_result_t *res) {
     if (!res) return;
+    if (res->pending) (void) hipEventSynchronize(res->done);
     for (DevBuf *b : res->all()) b->release();
     if (res->events) {
         for (auto &e : res->kev) (void) hipEventDestroy(e);
+        (void) hipEventDestroy(res->done);
+        (void) hipHostFree(res->hc);
     }
     delete res;
 }

@@ -213,8 +213,16 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
     uint32_t w_arg, uint32_t k, const PmapSlot *__restrict__ slots, uint32_t log2cap,
     const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
-    uint4 *__restrict__ tile_cnt) {
+    uint4 *__restrict__ tile_cnt, unsigned long long *__restrict__ state, uint32_t n_state_words,
+    uint32_t *__restrict__ hbounds, uint32_t n_hb) {
     const uint32_t w = WC ? (uint32_t) WC : w_arg;
+    {
+        // housekeeping for the kernels that follow in the stream: zero the counters and the words of
+        // the chained prefix sums, set the per-read hit bounds to all-ones
+        const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+        for (uint32_t i = gid; i < n_state_words; i += gsz) state[i] = 0ull;
+        for (uint32_t i = gid; i < n_hb; i += gsz) hbounds[i] = 0xFFFFFFFFu;
+    }
     __shared__ uint32_t sW[4][SK_NW], sStart[4][SK_NW], sLen[4][SK_NW], sRead[4][SK_NW];
     __shared__ __align__(16) HT sH[4][WAVE_POS];
     __shared__ __align__(16) uint32_t sJ[4][WAVE_POS];

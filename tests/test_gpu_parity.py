@@ -167,3 +167,32 @@ def test_errors(gpu):
     assert e.value.code == 5
     with pytest.raises(api.PmapError):
         api.Index.create(32, [], [0], [], [], [], [0], [], [], [])
+
+
+def test_async_batches_in_flight(gpu):
+    """pmap_map_async / pmap_map_wait: several batches enqueued before any is waited for, results
+    (including one that overflows its first buffers and is mapped again) equal to the blocking call."""
+    si, bases, off = _small_world(21, 14, 15, n_loci=30, n_reads=80)
+    gidx = gpu_index(si)
+    frac = api.fraction(0.11, 15)
+    parts = [(0, 10), (10, 50), (50, 80), (0, 80)]
+    reads = [api.Reads(bases[int(off[a]):int(off[b])], off[a:b + 1] - off[a], first_read_id=a) for a, b in parts]
+    want = []
+    for rd in reads:
+        r = api.map_reads(gidx, rd, 14, 15, 250, frac)
+        want.append((r.counts(), r.hits(), r.clusters()))
+    # small batch first: the carried-over capacities are too small for the batches after it
+    flying = [api.map_reads(gidx, rd, 14, 15, 250, frac, wait=False) for rd in reads]
+    for r, (cn, hits, cl) in zip(flying, want):
+        got = r.wait().counts()
+        for f in ("n_minimizers", "n_hits", "n_clusters_all", "n_clusters"):
+            assert got[f] == cn[f]
+        gh, gc = r.hits(), r.clusters()
+        for f in hits:
+            np.testing.assert_array_equal(gh[f], hits[f])
+        for f in cl:
+            np.testing.assert_array_equal(gc[f], cl[f])
+    # one result object reused while its run is still in flight: the second call waits for the first
+    r = api.map_reads(gidx, reads[3], 14, 15, 250, frac, wait=False)
+    r = api.map_reads(gidx, reads[1], 14, 15, 250, frac, result=r, wait=False)
+    assert r.counts()["n_hits"] == want[1][0]["n_hits"]
