@@ -25,22 +25,88 @@ struct Quad {
     HT v[4];
 };
 
-// 16-byte LDS read of quad q.  The empty asm marks every component as used: left alone, the
-// compiler narrows the read to the components a window shape needs, and dword reads at a 16-byte
-// lane stride hit 8 of the 32 banks (4-way conflicts), while the full ds_read_b128 is conflict-free.
+// 16-byte LDS reads of whole quads, issued by hand: written as plain loads the compiler narrows
+// them to the components a window shape needs, and dword reads at a 16-byte lane stride hit 8 of
+// the 32 banks (4-way conflicts), while a full ds_read_b128 is conflict-free.  ldq_issue starts the
+// read of quad q; the data may be used only after lds_wait() and then lds_arrive() on the quad (the
+// wait covers every read issued so far; lds_arrive ties the quad's registers to a point after it,
+// so that no use of them can be scheduled before the wait).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename HT>
+struct QuadRaw {
+    u32x4 lo, hi;   // hi only for 8-byte elements
+};
+
+__device__ __forceinline__ u32x4 lds_read_b128(const void *p) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"((uint32_t) (uintptr_t) p) : "memory");
+    return r;
+}
+
+template <typename HT>
+__device__ __forceinline__ QuadRaw<HT> ldq_issue(const HT *a, int q) {
+    QuadRaw<HT> r;
+    r.lo = lds_read_b128(a + 4 * q);
+    if (sizeof(HT) == 8) r.hi = lds_read_b128(a + 4 * q + 2);
+    return r;
+}
+
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <typename HT>
+__device__ __forceinline__ void lds_arrive(QuadRaw<HT> &r) {
+    if (sizeof(HT) == 8) asm volatile("" : "+v"(r.lo), "+v"(r.hi));
+    else asm volatile("" : "+v"(r.lo));
+}
+
+template <typename HT>
+__device__ __forceinline__ Quad<HT> unraw(const QuadRaw<HT> &r) {
+    Quad<HT> q;
+    if (sizeof(HT) == 4) {
+        q.v[0] = (HT) r.lo.x; q.v[1] = (HT) r.lo.y; q.v[2] = (HT) r.lo.z; q.v[3] = (HT) r.lo.w;
+    } else {
+        q.v[0] = (HT) (((uint64_t) r.lo.y << 32) | r.lo.x); q.v[1] = (HT) (((uint64_t) r.lo.w << 32) | r.lo.z);
+        q.v[2] = (HT) (((uint64_t) r.hi.y << 32) | r.hi.x); q.v[3] = (HT) (((uint64_t) r.hi.w << 32) | r.hi.z);
+    }
+    return q;
+}
+
+// the quads base + step * i, i = 0..n-1 (n <= SK_MAXRUN), read together with the quads x0, x1, x2
+static const int SK_MAXRUN = 4;
+template <typename HT>
+struct QuadSet {
+    Quad<HT> x0, x1, x2, run[SK_MAXRUN];
+};
+
+template <typename HT>
+__device__ __forceinline__ QuadSet<HT> ldq_set(const HT *a, int q0, int q1, int q2, int run0, int n) {
+    QuadRaw<HT> r0 = ldq_issue(a, q0), r1 = ldq_issue(a, q1), r2 = ldq_issue(a, q2), rr[SK_MAXRUN];
+#pragma unroll
+    for (int i = 0; i < SK_MAXRUN; ++i)
+        if (i < n) rr[i] = ldq_issue(a, run0 + i);
+    lds_wait();
+    lds_arrive(r0);
+    lds_arrive(r1);
+    lds_arrive(r2);
+    QuadSet<HT> s;
+    s.x0 = unraw(r0); s.x1 = unraw(r1); s.x2 = unraw(r2);
+#pragma unroll
+    for (int i = 0; i < SK_MAXRUN; ++i)
+        if (i < n) {
+            lds_arrive(rr[i]);
+            s.run[i] = unraw(rr[i]);
+        }
+    return s;
+}
+
+// one quad, waited for at once (window shapes with long runs)
 template <typename HT>
 __device__ __forceinline__ Quad<HT> ldq(const HT *a, int q) {
-    Quad<HT> r;
-    if (sizeof(HT) == 4) {
-        uint4 x = *(const uint4 *) (a + 4 * q);
-        asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-        r.v[0] = (HT) x.x; r.v[1] = (HT) x.y; r.v[2] = (HT) x.z; r.v[3] = (HT) x.w;
-    } else {
-        ulonglong2 x = *(const ulonglong2 *) (a + 4 * q), y = *(const ulonglong2 *) (a + 4 * q + 2);
-        asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(y.x), "+v"(y.y));
-        r.v[0] = (HT) x.x; r.v[1] = (HT) x.y; r.v[2] = (HT) y.x; r.v[3] = (HT) y.y;
-    }
-    return r;
+    QuadRaw<HT> r = ldq_issue(a, q);
+    lds_wait();
+    lds_arrive(r);
+    return unraw(r);
 }
 
 template <typename HT>
@@ -98,8 +164,11 @@ __device__ __forceinline__ uint32_t hash64_u32(uint32_t key, uint32_t mask, cons
     key = lshl_add<8>(key, lshl_add<3>(key, key));
     key ^= __builtin_amdgcn_ubfe(key, 14u, hw.w14);
     key = lshl_add<4>(key, lshl_add<2>(key, key));
-    key ^= __builtin_amdgcn_ubfe(key, 28u, hw.w28);
-    return key & mask;
+    // (key ^ field) & mask in one three-input bit operation (truth table 0x28 = (a ^ b) & c)
+    const uint32_t t = __builtin_amdgcn_ubfe(key, 28u, hw.w28);
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(r) : "v"(key), "v"(t), "v"(mask));
+    return r;
 }
 
 // reverse complement of 16 bases held in 32 bits (2 bits per base, first base on top)
@@ -124,11 +193,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // a = 4f + p >= 4.  Window of position 4Q+j starts at 4(Q-f) + j - p.
 template <typename HT>
 __device__ __forceinline__ Quad<HT> window_min_back(const HT *h, int Q, int f, int p) {
-    const Quad<HT> own = ldq(h, Q), v = ldq(h, Q - f);
-    Quad<HT> u = v;
-    if (p) u = ldq(h, Q - f - 1);
+    // own quad, the two boundary quads, and the f-1 whole quads in between
+    const int nmid = f - 1;
+    const QuadSet<HT> qs = ldq_set(h, Q, Q - f, p ? Q - f - 1 : Q - f, Q - f + 1, nmid < SK_MAXRUN ? nmid : SK_MAXRUN);
+    const Quad<HT> own = qs.x0, v = qs.x1, u = qs.x2;
     HT mid = (HT) ~(HT) 0;
-    for (int q = Q - f + 1; q < Q; ++q) {
+#pragma unroll
+    for (int i = 0; i < SK_MAXRUN; ++i)
+        if (i < nmid) {
+            const Quad<HT> &m = qs.run[i];
+            mid = tmin(mid, tmin(tmin(m.v[0], m.v[1]), tmin(m.v[2], m.v[3])));
+        }
+    for (int q = Q - f + 1 + SK_MAXRUN; q < Q; ++q) {
         const Quad<HT> m = ldq(h, q);
         mid = tmin(mid, tmin(tmin(m.v[0], m.v[1]), tmin(m.v[2], m.v[3])));
     }
@@ -153,11 +229,17 @@ __device__ __forceinline__ Quad<HT> window_min_back(const HT *h, int Q, int f, i
 // Window of position 4Q+j ends at 4(Q+f) + j + p.
 template <typename HT>
 __device__ __forceinline__ Quad<HT> window_max_fwd(const HT *L, int Q, int f, int p) {
-    const Quad<HT> own = ldq(L, Q), v = ldq(L, Q + f);
-    Quad<HT> u = v;
-    if (p) u = ldq(L, Q + f + 1);
+    const int nmid = f - 1;
+    const QuadSet<HT> qs = ldq_set(L, Q, Q + f, p ? Q + f + 1 : Q + f, Q + 1, nmid < SK_MAXRUN ? nmid : SK_MAXRUN);
+    const Quad<HT> own = qs.x0, v = qs.x1, u = qs.x2;
     HT mid = 0;
-    for (int q = Q + 1; q < Q + f; ++q) {
+#pragma unroll
+    for (int i = 0; i < SK_MAXRUN; ++i)
+        if (i < nmid) {
+            const Quad<HT> &m = qs.run[i];
+            mid = tmax(mid, tmax(tmax(m.v[0], m.v[1]), tmax(m.v[2], m.v[3])));
+        }
+    for (int q = Q + 1 + SK_MAXRUN; q < Q + f; ++q) {
         const Quad<HT> m = ldq(L, q);
         mid = tmax(mid, tmax(tmax(m.v[0], m.v[1]), tmax(m.v[2], m.v[3])));
     }
@@ -234,7 +316,6 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     uint32_t *W = sW[wv], *mstart = sStart[wv], *mlen = sLen[wv], *wr = sRead[wv];
     HT *h = sH[wv], *Lv = sL[wv];
     uint32_t *jv = sJ[wv];
-    const HT INVALID = (HT) ~(HT) 0;
 
     const int a = (int) w - 1, f = a >> 2, p = a & 3;
     const int edge = f + (p ? 1 : 0);
@@ -271,16 +352,20 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     const uint32_t mis = ((uint32_t) lane + (off0 >> 2)) & 3u;     // quad inside its packed word
     uint32_t bsel = mis | (mis << 8);
     bsel = 0x07060504u - (bsel | (bsel << 16));
+    // Positions that are no k-mer of a read (padding, reads too short or with a bad letter) get
+    // hashes of whatever bits are there: they never reach a result, because a window minimum counts
+    // only if its whole window lies inside one read, and a flag only at a real k-mer.
     Quad<HT> own[SK_NQ];
-    uint32_t jj[SK_NQ][4];
+    int lim[SK_NQ], lo[SK_NQ];      // k-mer j of the quad exists iff j <= lim; its full backward window iff also j >= lo
 #pragma unroll
     for (int hq = 0; hq < SK_NQ; ++hq) {
         const int Q = lane + 64 * hq;
         const int wi = (int) ((4u * (uint32_t) Q + off0) >> 4);
         const uint32_t len = mlen[wi];
         const uint32_t j0 = P0lo + 4u * (uint32_t) Q - mstart[wi];     // position of the quad inside its read
-        // k-mer j0 + j exists iff j <= lim
-        const int lim = len ? (int) (len - k - j0) : -1;
+        lim[hq] = len ? (int) (len - k - j0) : -1;
+        lo[hq] = a - (int) j0;
+        uint32_t jj[4];
         const uint32_t w0 = W[wi], w1 = W[wi + 1], w2 = W[wi + 2];
         // 64 stream bits starting at the quad's first base
         const uint32_t x0 = __builtin_amdgcn_perm(w0, w1, bsel), x1 = __builtin_amdgcn_perm(w1, w2, bsel);
@@ -294,11 +379,9 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
                 const uint32_t fwd = top >> (32 - 2 * k);
                 const uint32_t rc = j ? __builtin_amdgcn_alignbit(yhi, ylo, 2 * j) : ylo;
                 const uint32_t hf = hash64_u32(fwd, mask, hw), hr = hash64_u32(rc, mask, hw);
-                const bool ok = j <= lim;
                 // hashes are below 2^30: the sign of hr - hf tells hf > hr; strand = (hf <= hr)
-                const uint32_t ps = (j0 + j) | (~(hr - hf) & 0x80000000u);
-                own[hq].v[j] = ok ? tmin(hf, hr) : INVALID;
-                jj[hq][j] = ok ? ps : SK_NOKMER;
+                jj[j] = (j0 + j) | (~(hr - hf) & 0x80000000u);
+                own[hq].v[j] = tmin(hf, hr);
             }
         } else {
             const uint32_t w3 = W[wi + 3];
@@ -314,13 +397,12 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
                 if (j == 0) rc = revcomp_dev(fwd, k);
                 else rc = (rc >> 2) | ((uint64_t) (3u ^ ((uint32_t) fwd & 3u)) << (2 * k - 2));
                 const uint64_t hf = hash64_dev<uint64_t>(fwd, mask), hr = hash64_dev<uint64_t>(rc, mask);
-                const bool ok = j <= lim;
-                own[hq].v[j] = ok ? tmin(hf, hr) : INVALID;
-                jj[hq][j] = ok ? ((j0 + j) | ((hf <= hr ? 1u : 0u) << 31)) : SK_NOKMER;
+                own[hq].v[j] = tmin(hf, hr);
+                jj[j] = (j0 + j) | ((hf <= hr ? 1u : 0u) << 31);
             }
         }
         stq(h, Q, own[hq]);
-        *(uint4 *) (jv + 4 * Q) = make_uint4(jj[hq][0], jj[hq][1], jj[hq][2], jj[hq][3]);
+        *(uint4 *) (jv + 4 * Q) = make_uint4(jj[0], jj[1], jj[2], jj[3]);
     }
     wave_lds_sync();
 
@@ -342,7 +424,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (jj[hq][j] == SK_NOKMER || (jj[hq][j] & 0x7FFFFFFFu) < (uint32_t) a) m.v[j] = 0;
+            if (j > lim[hq] || j < lo[hq]) m.v[j] = 0;
         stq(Lv, Q, m);
     }
     wave_lds_sync();
@@ -366,7 +448,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fl[hq][j] = inr && jj[hq][j] != SK_NOKMER && mx.v[j] == own[hq].v[j];
+        for (int j = 0; j < 4; ++j) fl[hq][j] = inr && j <= lim[hq] && mx.v[j] == own[hq].v[j];
     }
     wave_lds_sync();                                // every lane has read Lv: it becomes the list of minimizer positions
 
