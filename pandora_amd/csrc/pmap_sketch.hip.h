@@ -307,7 +307,6 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     }
     __shared__ uint32_t sW[4][SK_NW], sStart[4][SK_NW], sLen[4][SK_NW], sRead[4][SK_NW];
     __shared__ __align__(16) HT sH[4][WAVE_POS];
-    __shared__ __align__(16) uint32_t sJ[4][WAVE_POS];
     __shared__ __align__(16) HT sL[4][WAVE_POS + 8];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -315,7 +314,6 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     if (g >= n_tiles) return;                       // whole wavefront leaves; nothing below uses a block barrier
     uint32_t *W = sW[wv], *mstart = sStart[wv], *mlen = sLen[wv], *wr = sRead[wv];
     HT *h = sH[wv], *Lv = sL[wv];
-    uint32_t *jv = sJ[wv];
 
     const int a = (int) w - 1, f = a >> 2, p = a & 3;
     const int edge = f + (p ? 1 : 0);
@@ -357,6 +355,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     // only if its whole window lies inside one read, and a flag only at a real k-mer.
     Quad<HT> own[SK_NQ];
     int lim[SK_NQ], lo[SK_NQ];      // k-mer j of the quad exists iff j <= lim; its full backward window iff also j >= lo
+    uint32_t nstrand = 0;           // bit 7 - (4 hq + j): h_fwd > h_rc at position j of quad hq, i.e. strand = 0
 #pragma unroll
     for (int hq = 0; hq < SK_NQ; ++hq) {
         const int Q = lane + 64 * hq;
@@ -365,7 +364,6 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
         const uint32_t j0 = P0lo + 4u * (uint32_t) Q - mstart[wi];     // position of the quad inside its read
         lim[hq] = len ? (int) (len - k - j0) : -1;
         lo[hq] = a - (int) j0;
-        uint32_t jj[4];
         const uint32_t w0 = W[wi], w1 = W[wi + 1], w2 = W[wi + 2];
         // 64 stream bits starting at the quad's first base
         const uint32_t x0 = __builtin_amdgcn_perm(w0, w1, bsel), x1 = __builtin_amdgcn_perm(w1, w2, bsel);
@@ -380,7 +378,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
                 const uint32_t rc = j ? __builtin_amdgcn_alignbit(yhi, ylo, 2 * j) : ylo;
                 const uint32_t hf = hash64_u32(fwd, mask, hw), hr = hash64_u32(rc, mask, hw);
                 // hashes are below 2^30: the sign of hr - hf tells hf > hr; strand = (hf <= hr)
-                jj[j] = (j0 + j) | (~(hr - hf) & 0x80000000u);
+                nstrand = __builtin_amdgcn_alignbit(nstrand, hr - hf, 31);   // nstrand << 1 | sign
                 own[hq].v[j] = tmin(hf, hr);
             }
         } else {
@@ -398,11 +396,10 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
                 else rc = (rc >> 2) | ((uint64_t) (3u ^ ((uint32_t) fwd & 3u)) << (2 * k - 2));
                 const uint64_t hf = hash64_dev<uint64_t>(fwd, mask), hr = hash64_dev<uint64_t>(rc, mask);
                 own[hq].v[j] = tmin(hf, hr);
-                jj[j] = (j0 + j) | ((hf <= hr ? 1u : 0u) << 31);
+                nstrand = nstrand << 1 | (hf > hr ? 1u : 0u);
             }
         }
         stq(h, Q, own[hq]);
-        *(uint4 *) (jv + 4 * Q) = make_uint4(jj[0], jj[1], jj[2], jj[3]);
     }
     wave_lds_sync();
 
@@ -452,7 +449,8 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     }
     wave_lds_sync();                                // every lane has read Lv: it becomes the list of minimizer positions
 
-    // ---- compaction in position order with ballots: list[e] = index (4 * quad + j) of the e-th minimizer
+    // ---- compaction in position order with ballots: list[e] = index (4 * quad + j) of the e-th
+    // minimizer, with its strand in bit 16
     uint32_t *list = (uint32_t *) Lv;
     uint32_t n = 0;
 #pragma unroll
@@ -468,7 +466,8 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
         n += c;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (fl[hq][j]) list[o++] = 4u * (uint32_t) (lane + 64 * hq) + j;
+            if (fl[hq][j])
+                list[o++] = (4u * (uint32_t) (lane + 64 * hq) + j) | ((~nstrand >> (7 - (4 * hq + j)) & 1u) << 16);
     }
     wave_lds_sync();
 
@@ -479,10 +478,10 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
         uint32_t cnt = 0, off = 0, ps = 0, rd = 0;
         HT hv = 0;
         if (e < n) {
-            const uint32_t i = list[e];
+            const uint32_t le = list[e], i = le & 0xFFFFu, wi = (i + off0) >> 4;
             hv = h[i];
-            ps = jv[i];
-            rd = wr[(i + off0) >> 4];
+            ps = (P0lo + i - mstart[wi]) | (le >> 16) << 31;     // position inside the read, strand on top
+            rd = wr[wi];
         }
         if (!FUSED) {
             if (e < n) {
