@@ -330,6 +330,14 @@ struct KTimer {
 };
 static KTimer *g_kt = nullptr;
 
+#define KLAUNCH_B(kernel, grid, block, ...)                                                                 \
+    do {                                                                                                    \
+        hipEvent_t s_ = nullptr, e_ = nullptr;                                                              \
+        if (g_kt) g_kt->events(&s_, &e_);                                                                   \
+        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(block), 0, g_stream, s_, e_, 0, __VA_ARGS__); \
+        else kernel<<<grid, dim3(block), 0, g_stream>>>(__VA_ARGS__);                                       \
+    } while (0)
+// (not written in terms of KLAUNCH_B: a second expansion would split template arguments at their commas)
 #define KLAUNCH(kernel, grid, ...)                                                                        \
     do {                                                                                                  \
         hipEvent_t s_ = nullptr, e_ = nullptr;                                                            \
@@ -382,9 +390,9 @@ static int run_pipeline(pmap_result *res) {
     const bool k32 = k <= 15;
     const uint32_t n_tiles = res->n_tiles;
     // state block: counters + one 8-byte word per block of each chained prefix sum
-    res->n_sblk = (n_tiles + 255) / 256;
+    res->n_sblk = (n_tiles + SCATTER_WAVES * SCATTER_TILES - 1) / (SCATTER_WAVES * SCATTER_TILES);
     res->n_ablk = res->hit_cap / CUT_BLOCK;
-    res->n_bblk = res->cl_cap / 256;
+    res->n_bblk = res->cl_cap / KEEP_THREADS;
     const size_t state_bytes =
         (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_sblk + res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
     if ((rc = res->state.ensure(state_bytes))) return rc;
@@ -438,7 +446,7 @@ static int run_pipeline(pmap_result *res) {
             kt.end(KT_PROBE);
         }
         kt.begin(KT_SCATTER);
-        KLAUNCH(scatter_group_kernel, dim3(res->n_sblk), res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
+        KLAUNCH_B(scatter_group_kernel, dim3(res->n_sblk), 64 * SCATTER_WAVES, res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
                 idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, gran_s, rd->n_reads + 1, res->hbounds.as<uint32_t>(),
                 res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
                 res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
@@ -462,12 +470,12 @@ static int run_pipeline(pmap_result *res) {
     // ---- cluster
     if (last >= PMAP_STAGE_CLUSTER && n_tiles) {
         kt.begin(KT_CLUSTER_CUT);
-        KLAUNCH(cluster_cut_kernel, dim3(res->n_ablk), dc, res->hit_cap, res->s_read.as<uint32_t>(),
+        KLAUNCH_B(cluster_cut_kernel, dim3(res->n_ablk), CUT_THREADS, dc, res->hit_cap, res->s_read.as<uint32_t>(),
                 res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), (int) prm->max_diff, gran_a, res->cl_cap,
                 res->cstart.as<uint32_t>());
         kt.end(KT_CLUSTER_CUT);
         kt.begin(KT_CLUSTER_KEEP);
-        KLAUNCH(cluster_keep_kernel, dim3(res->n_bblk), dc, res->cl_cap, res->hit_cap, res->cstart.as<uint32_t>(),
+        KLAUNCH_B(cluster_keep_kernel, dim3(res->n_bblk), KEEP_THREADS, dc, res->cl_cap, res->hit_cap, res->cstart.as<uint32_t>(),
                 res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(),
                 res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), gran_b, res->k_rows.as<uint32_t>());
         kt.end(KT_CLUSTER_KEEP);
@@ -565,7 +573,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     // capacities of the data-dependent buffers: carried over from earlier calls, grown on overflow
     if (res->hit_cap == 0 && (rc = ensure_hit_buffers(res, round_up(std::max<uint64_t>(n_tiles * 8ull, 4096), CUT_BLOCK))))
         return rc;
-    if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), 256))))
+    if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), KEEP_THREADS))))
         return rc;
 
     res->p_idx = idx;
@@ -604,7 +612,7 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         // at most one cluster per hit; when the hits overflowed the cluster count is only a lower bound
         if (last >= PMAP_STAGE_CLUSTER && (hc.n_cl > res->cl_cap || (again && res->cl_cap < res->hit_cap / 8))) {
             const uint64_t want = std::max<uint64_t>(hc.n_cl + hc.n_cl / 8, res->hit_cap / 8);
-            if ((rc = ensure_cluster_buffers(res, round_up(std::min<uint64_t>(want, res->hit_cap), 256)))) return rc;
+            if ((rc = ensure_cluster_buffers(res, round_up(std::min<uint64_t>(want, res->hit_cap), KEEP_THREADS)))) return rc;
             again = true;
         }
         if (!again) break;

@@ -43,8 +43,9 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
     if (lane == 0) ((uint32_t *) (tile_cnt + g))[2] = mine;
 }
 
-// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A block takes 256 tiles, a wavefront
-// 64 of them.  The block's first hit is the chained prefix sum of the blocks'
+// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A block of 16 wavefronts takes 256
+// tiles, a wavefront 16 of them (the work of a wavefront is a chain of dependent loads: many short
+// chains hide the latency better than few long ones).  The block's first hit is the chained prefix sum of the blocks'
 // hit counts; batch totals are added to the counters.  A wavefront numbers its entries
 // consecutively (tile by tile, so still in (read, position) order); lane e takes entry e, finds
 // its tile by a search over the per-tile prefix sums held in the lanes, and writes the entry's
@@ -53,19 +54,21 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
 // all-ones and are lowered with atomic minima where the read index changes between consecutive
 // entries and at the first and last entry of every wavefront.
 // emit = 0: totals only.
-__global__ __launch_bounds__(256) void scatter_group_kernel(
+static const uint32_t SCATTER_WAVES = 16, SCATTER_TILES = 64;   // per block, per wavefront
+
+__global__ __launch_bounds__(1024) void scatter_group_kernel(
     const uint4 *__restrict__ tile_cnt, uint32_t n_tiles, const uint4 *__restrict__ ents,
     const PmapRec *__restrict__ recs, uint32_t hit_cap, uint32_t emit, Counters *__restrict__ dc,
     unsigned long long *__restrict__ gran, uint32_t n_reads, uint32_t *__restrict__ hbounds,
     uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key, uint32_t *__restrict__ h_pos,
     uint32_t *__restrict__ h_rank, uint32_t *__restrict__ h_rec) {
-    __shared__ uint32_t s_w[4][3];
+    __shared__ uint32_t s_w[SCATTER_WAVES][3];
     __shared__ uint32_t s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t t0 = (b * 4 + wv) * 64, t = t0 + lane;
+    const uint32_t t0 = (b * SCATTER_WAVES + wv) * SCATTER_TILES, t = t0 + lane;
     uint4 c = make_uint4(0, 0, 0, 0);
-    if (t < n_tiles) c = tile_cnt[t];
+    if (lane < SCATTER_TILES && t < n_tiles) c = tile_cnt[t];
     const uint32_t n = c.y;
     uint32_t E;
     const uint32_t estart = wave_scan(n, &E);
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
     __syncthreads();
     uint32_t bm = 0, be = 0, bh = 0, before = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
+    for (uint32_t i = 0; i < SCATTER_WAVES; ++i) {
         bm += s_w[i][0];
         be += s_w[i][1];
         bh += s_w[i][2];
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
         // the tile of entry e: the largest T with estart[T] <= e
         uint32_t T = 0;
 #pragma unroll
-        for (uint32_t step = 32; step > 0; step >>= 1) {
+        for (uint32_t step = SCATTER_TILES / 2; step > 0; step >>= 1) {
             const uint32_t cand = T + step;
             const uint32_t v = __shfl(estart, cand & 63);
             if (v <= e) T = cand;

@@ -333,25 +333,26 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
 }
 
 // ---------------------------------------------------------------------------
-// cluster cut (src/utils.cpp:206-209).  A block takes 2048 sorted hits (8 rounds of
-// 256), flags the hits that start a cluster, and writes their indices to cstart at the chained
-// prefix sum of the blocks' flag counts.  The last block writes the cluster total.
-static const uint32_t CUT_ROUNDS = 8, CUT_BLOCK = 256 * CUT_ROUNDS;
+// cluster cut (src/utils.cpp:206-209).  A block of 1024 threads takes 8192 sorted hits (8 rounds of
+// 1024), flags the hits that start a cluster, and writes their indices to cstart at the chained
+// prefix sum of the blocks' flag counts.  The last block writes the cluster total.  Big blocks keep
+// the chain short: its cost grows with the number of blocks that poll each other's words.
+static const uint32_t CUT_THREADS = 1024, CUT_WAVES = CUT_THREADS / 64, CUT_ROUNDS = 8, CUT_BLOCK = CUT_THREADS * CUT_ROUNDS;
 
-__global__ __launch_bounds__(256) void cluster_cut_kernel(Counters *__restrict__ dc, uint32_t hit_cap,
-                                                          const uint32_t *__restrict__ s_read,
-                                                          const uint32_t *__restrict__ s_key,
-                                                          const uint32_t *__restrict__ s_pos, int max_diff,
-                                                          unsigned long long *__restrict__ gran, uint32_t cl_cap,
-                                                          uint32_t *__restrict__ cstart) {
-    __shared__ uint32_t s_cnt[CUT_ROUNDS * 4], s_scan[2];
+__global__ __launch_bounds__(1024) void cluster_cut_kernel(Counters *__restrict__ dc, uint32_t hit_cap,
+                                                           const uint32_t *__restrict__ s_read,
+                                                           const uint32_t *__restrict__ s_key,
+                                                           const uint32_t *__restrict__ s_pos, int max_diff,
+                                                           unsigned long long *__restrict__ gran, uint32_t cl_cap,
+                                                           uint32_t *__restrict__ cstart) {
+    __shared__ uint32_t s_cnt[CUT_ROUNDS * CUT_WAVES], s_half[2], s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
     uint32_t fbits = 0, rank[CUT_ROUNDS];
 #pragma unroll
     for (uint32_t r = 0; r < CUT_ROUNDS; ++r) {
-        const uint32_t i = b * CUT_BLOCK + r * 256 + threadIdx.x;
+        const uint32_t i = b * CUT_BLOCK + r * CUT_THREADS + threadIdx.x;
         bool f = false;
         if (i < n_hits) {
             if (i == 0) f = true;
@@ -363,47 +364,50 @@ __global__ __launch_bounds__(256) void cluster_cut_kernel(Counters *__restrict__
         const unsigned long long m = __ballot(f);
         rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
         if (f) fbits |= 1u << r;
-        if (lane == 0) s_cnt[r * 4 + wv] = (uint32_t) __popcll(m);
+        if (lane == 0) s_cnt[r * CUT_WAVES + wv] = (uint32_t) __popcll(m);
     }
     __syncthreads();
-    // exclusive scan of the 32 (round, wavefront) counts, in hit order
-    uint32_t total = 0, mine[CUT_ROUNDS];
-#pragma unroll
-    for (uint32_t r = 0; r < CUT_ROUNDS; ++r) {
-#pragma unroll
-        for (uint32_t v = 0; v < 4; ++v) {
-            if (v == wv) mine[r] = total;
-            total += s_cnt[r * 4 + v];
-        }
+    // exclusive scan of the 128 (round, wavefront) counts, which are in hit order, by wavefronts 0 and 1
+    static_assert(CUT_ROUNDS * CUT_WAVES == 128, "two wavefronts scan the counts");
+    uint32_t ex = 0;
+    if (wv < 2) {
+        uint32_t tot;
+        ex = wave_scan(s_cnt[threadIdx.x], &tot);
+        if (lane == 0) s_half[wv] = tot;
     }
-    const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);
+    __syncthreads();
+    const uint32_t total = s_half[0] + s_half[1];
+    if (wv < 2) s_cnt[threadIdx.x] = ex + (wv ? s_half[0] : 0u);
+    const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);   // has a block barrier after the writes above
 #pragma unroll
     for (uint32_t r = 0; r < CUT_ROUNDS; ++r)
         if (fbits >> r & 1u) {
-            const uint32_t c = excl + mine[r] + rank[r];
-            if (c < cl_cap) cstart[c] = b * CUT_BLOCK + r * 256 + threadIdx.x;
+            const uint32_t c = excl + s_cnt[r * CUT_WAVES + wv] + rank[r];
+            if (c < cl_cap) cstart[c] = b * CUT_BLOCK + r * CUT_THREADS + threadIdx.x;
         }
     if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_cl = (unsigned long long) excl + total;
 }
 
-// One thread per cluster, blocks of 256: size threshold (src/utils.cpp:211-220)
-// and, for the clusters kept, the summary row {first hit, size, read, prg << 1 | !forward, first
-// position, last position, path rank of the first hit, cluster number} at the chained prefix sum
-// of the kept counts.  The last block writes the kept total.
-__global__ __launch_bounds__(256) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
-                                                           uint32_t hit_cap, const uint32_t *__restrict__ cstart,
-                                                           const uint32_t *__restrict__ s_read,
-                                                           const uint32_t *__restrict__ s_key,
-                                                           const uint32_t *__restrict__ s_pos,
-                                                           const uint32_t *__restrict__ s_rank,
-                                                           const uint32_t *__restrict__ thr,
-                                                           unsigned long long *__restrict__ gran,
-                                                           uint32_t *__restrict__ k_rows) {
-    __shared__ uint32_t s_cnt[4], s_scan[2];
+// One thread per cluster, blocks of 1024: size threshold (src/utils.cpp:211-220) and, for the
+// clusters kept, the summary row {first hit, size, read, prg << 1 | !forward, first position, last
+// position, path rank of the first hit, cluster number} at the chained prefix sum of the kept
+// counts.  The last block writes the kept total.
+static const uint32_t KEEP_THREADS = 1024, KEEP_WAVES = KEEP_THREADS / 64;
+
+__global__ __launch_bounds__(1024) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
+                                                            uint32_t hit_cap, const uint32_t *__restrict__ cstart,
+                                                            const uint32_t *__restrict__ s_read,
+                                                            const uint32_t *__restrict__ s_key,
+                                                            const uint32_t *__restrict__ s_pos,
+                                                            const uint32_t *__restrict__ s_rank,
+                                                            const uint32_t *__restrict__ thr,
+                                                            unsigned long long *__restrict__ gran,
+                                                            uint32_t *__restrict__ k_rows) {
+    __shared__ uint32_t s_cnt[KEEP_WAVES], s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n_cl = clamp_count(&dc->n_cl, cl_cap), n_hits = clamp_count(&dc->n_hits, hit_cap);
-    const uint32_t c = b * 256 + threadIdx.x;
+    const uint32_t c = b * KEEP_THREADS + threadIdx.x;
     bool kept = false;
     uint32_t s = 0, e = 0, key = 0;
     if (c < n_cl) {
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(256) void cluster_keep_kernel(Counters *__restrict_
     __syncthreads();
     uint32_t total = 0, before = 0;
 #pragma unroll
-    for (uint32_t v = 0; v < 4; ++v) {
+    for (uint32_t v = 0; v < KEEP_WAVES; ++v) {
         if (v == wv) before = total;
         total += s_cnt[v];
     }

@@ -17,8 +17,7 @@ import os
 import sys
 
 PHASE_OF = [("sketch_wave", "sketch"), ("probe_wave", "probe"), ("scan_", None), ("scatter_group", "probe"),
-            ("seg_bounds", "probe"), ("sort_rank", "sort"), ("cluster_flags", "cluster"), ("bit_positions", "cluster"),
-            ("cluster_table", "cluster"), ("cluster_gather", "cluster")]
+            ("sort_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
 
 
 def per_kernel(path):
