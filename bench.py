@@ -99,13 +99,19 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # PANDORA_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("PANDORA_BENCH_BACKEND", "nccl")
+    device = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     import pandora_amd
     from pandora_amd import api, synth
-    pandora_amd.init(local_rank)
+    pandora_amd.init(device)
 
     # same index on every rank (replicated), a different shard of reads per rank
     si, bases, offsets, prm = synth.workload(args.workload, seed=1, scale=args.scale, shard=rank)
@@ -133,7 +139,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[device]) if backend == "nccl" else dist.barrier()
 
     kernel_ms, sketch_ms = {}, 0.0
     sync()
@@ -171,8 +177,9 @@ def main():
     if prof:
         kernel_ms["sketch"] = sketch_ms
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(cn["n_bases"]), float(cn["n_hits"])], dtype=torch.float64, device="cuda")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(cn["n_bases"]), float(cn["n_hits"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -234,7 +241,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[device]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,100 @@
+"""The bench workload at its full size (1 000 loci, 10 000 nanopore reads, 1e8 bases) through the C ABI.
+The oracle needs seconds per thousand reads, so the whole batch is checked through properties that do
+not depend on size, and slices of it against the oracle itself."""
+import numpy as np
+import pytest
+
+from pandora_amd import api, synth
+from parity import compare_batch, gpu_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(gpu):
+    si, bases, off, prm = synth.workload("nanopore_1k", seed=1)
+    gidx = gpu_index(si)
+    frac = api.fraction(prm["e_rate"], prm["k"])
+    rd = api.Reads(bases, off)
+    res = api.map_reads(gidx, rd, prm["w"], prm["k"], prm["max_diff"], frac, prm["min_cluster_size"])
+    yield dict(si=si, bases=bases, off=off, prm=prm, gidx=gidx, frac=frac, res=res,
+               hits=res.hits(), clusters=res.clusters(), counts=res.counts())
+    res.close()
+    rd.close()
+    gidx.close()
+
+
+def test_hit_order_and_cluster_invariants(world):
+    h, c, cn, si, prm = world["hits"], world["clusters"], world["counts"], world["si"], world["prm"]
+    assert cn["n_bases"] > 9e7 and cn["n_hits"] > 1e6 and cn["n_clusters"] > 1e4
+    # MinimizerHit::operator< (src/minihit.cpp:44-66): read, prg, forward first, position (then path)
+    assert h["prg"].max() < (1 << 11) and h["pos"].max() < (1 << 31) and h["read"].max() < (1 << 18)
+    coarse = (h["read"].astype(np.int64) << 44) | (h["prg"].astype(np.int64) << 33) | \
+             ((1 - h["fwd"].astype(np.int64)) << 32) | h["pos"].astype(np.int64)
+    assert (np.diff(coarse) >= 0).all()
+    # every hit is a record of the k-mer's key with the right orientation
+    assert (h["prg"] == si.rec_prg[h["rec"]]).all()
+    # clusters: disjoint runs of hits of one (read, prg, strand), gaps within max_diff, size above the threshold
+    b, s = c["begin"].astype(np.int64), c["size"].astype(np.int64)
+    assert (np.diff(b) > 0).all() and (b[:-1] + s[:-1] <= b[1:]).all() and b[-1] + s[-1] <= cn["n_hits"]
+    assert (h["read"][b] == c["read"]).all() and (h["prg"][b] == c["prg"]).all() and (h["fwd"][b] == c["fwd"]).all()
+    last = b + s - 1
+    assert (h["read"][last] == c["read"]).all() and (h["prg"][last] == c["prg"]).all()
+    assert (h["pos"][b] == c["first_pos"]).all() and (h["pos"][last] == c["last_pos"]).all()
+    thr = np.maximum((np.minimum(si.min_path_length, 0xFFFFFFFF).astype(np.float32)
+                      * np.float32(world["frac"])).astype(np.uint32), prm["min_cluster_size"])
+    assert (c["size"] > thr[c["prg"]]).all()
+    inside = np.ones(cn["n_hits"], bool)
+    inside[b] = False                 # first hit of a kept cluster may follow any gap
+    same = (h["read"][1:] == h["read"][:-1]) & (h["prg"][1:] == h["prg"][:-1]) & (h["fwd"][1:] == h["fwd"][:-1])
+    gap = np.abs(h["pos"][1:].astype(np.int64) - h["pos"][:-1].astype(np.int64))
+    member = np.zeros(cn["n_hits"] + 1, np.int64)
+    np.add.at(member, b, 1)
+    np.add.at(member, b + s, -1)
+    member = np.cumsum(member)[:-1] > 0
+    link = member[1:] & inside[1:]    # hit i+1 continues the kept cluster of hit i
+    assert (same[link]).all() and (gap[link] <= prm["max_diff"]).all()
+
+
+def test_batch_split_invariance(world):
+    """Mapping the reads in three uneven batches gives the hits and clusters of the single batch."""
+    off, bases, prm, gidx, frac = world["off"], world["bases"], world["prm"], world["gidx"], world["frac"]
+    n = len(off) - 1
+    cuts = [0, n // 7, n // 2 + 3, n]
+    got_h = {f: [] for f in world["hits"]}
+    got_c = {f: [] for f in world["clusters"]}
+    base_hit = 0
+    res = None
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rd = api.Reads(bases[int(off[a]):int(off[b])], off[a:b + 1] - off[a], first_read_id=a)
+        res = api.map_reads(gidx, rd, prm["w"], prm["k"], prm["max_diff"], frac, prm["min_cluster_size"], result=res)
+        h, c = res.hits(), res.clusters()
+        for f in got_h:
+            got_h[f].append(h[f])
+        c["begin"] = c["begin"] + base_hit
+        for f in got_c:
+            got_c[f].append(c[f])
+        base_hit += len(h["read"])
+        rd.close()
+    res.close()
+    for f in got_h:
+        np.testing.assert_array_equal(np.concatenate(got_h[f]), world["hits"][f], err_msg=f)
+    for f in got_c:
+        np.testing.assert_array_equal(np.concatenate(got_c[f]), world["clusters"][f], err_msg=f)
+
+
+@pytest.mark.parametrize("first,count", [(0, 150), (4321, 150), (9850, 150)])
+def test_slices_against_oracle(world, first, count):
+    """Slices of the same reads, against the full-size index, stage by stage against the oracle; and the
+    slice's rows inside the full-batch result."""
+    off, bases, prm, si = world["off"], world["bases"], world["prm"], world["si"]
+    sub_off = off[first:first + count + 1]
+    sub = bases[int(sub_off[0]):int(sub_off[-1])]
+    cn, orc = compare_batch(si, sub, sub_off - sub_off[0], prm["w"], prm["k"], prm["max_diff"], world["frac"],
+                            prm["min_cluster_size"], first_read_id=first, gidx=world["gidx"])
+    h = world["hits"]
+    sel = (h["read"] >= first) & (h["read"] < first + count)
+    assert sel.sum() == cn["n_hits"]
+    np.testing.assert_array_equal(h["pos"][sel], orc["hit_pos"])
+    np.testing.assert_array_equal(h["rec"][sel], orc["hit_rec"])
+    np.testing.assert_array_equal(h["prg"][sel], orc["hit_prg"])
