@@ -197,17 +197,26 @@ def main():
                           "GBps": (algo[ph] / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
                           "kernels": {k: kernel_ms.get(k, 0.0) for k in ks}}
         dom = max(phases, key=lambda p: phases[p]["ms"])
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                rec = json.load(open(pmc)).get(args.workload, {})
+                traffic = rec.get(dom)
+                # the sketch kernel is bounded by integer VALU issue: wavefront instructions per launch (PMC
+                # SQ_INSTS_VALU, same workload) against 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles
+                if dom == "sketch" and rec.get("sketch_valu_insts") and args.scale == 1.0:
+                    peak = 256 * 4 * 2.4e9 / 4
+                    rate = rec["sketch_valu_insts"] / (phases[dom]["ms"] * 1e-3)
+                    valu = {"wave_insts_per_launch": rec["sketch_valu_insts"], "achieved_insts_per_s": rate,
+                            "peak_insts_per_s": peak, "frac": rate / peak,
+                            "note": "VALU issue roofline at 2.4 GHz; the kernel's binding limit"}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         roofline = {"bound": "hbm", "kernel": "%s phase (%s)" % (dom, "+".join(PHASES[dom])),
                     "achieved": phases[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": phases[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "ms_per_launch": phases[dom]["ms"], "algorithmic_bytes_per_launch": algo[dom]}
+                    "ms_per_launch": phases[dom]["ms"], "algorithmic_bytes_per_launch": algo[dom], "valu": valu}
         out = {
             "metric": "read bases mapped/sec (sketch+probe+cluster)",
             "value": total_bases * args.steps / elapsed,

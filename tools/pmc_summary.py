@@ -4,6 +4,9 @@
     python tools/pmc_summary.py counters <counter_collection.csv>...
         per-kernel averages of every counter in the files
 
+    python tools/pmc_summary.py valu <workload> <sq.csv> [out.json]
+        SQ_INSTS_VALU per launch of the sketch kernel, merged into out.json (bench.py: roofline.valu)
+
     python tools/pmc_summary.py traffic <workload> <fetch.csv> <write.csv> [out.json]
         HBM-side bytes per launch of each phase of the path: FETCH_SIZE and WRITE_SIZE are reported in
         KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled.
@@ -75,8 +78,23 @@ def traffic(workload, fetch_csv, write_csv, out):
     print(json.dumps(res, indent=1))
 
 
+def valu(workload, sq_csv, out):
+    """SQ_INSTS_VALU (wavefront instructions) per launch of the sketch kernel, merged into out.json"""
+    vals = []
+    for k, d in per_kernel(sq_csv).items():
+        if "sketch_wave" in k and d.get("SQ_INSTS_VALU"):
+            vals += d["SQ_INSTS_VALU"]
+    cur = json.load(open(out)) if os.path.exists(out) else {}
+    cur.setdefault(workload, {})["sketch_valu_insts"] = sum(vals) / max(len(vals), 1)
+    json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
+    print(cur[workload]["sketch_valu_insts"])
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "counters":
+    default_out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
+    if sys.argv[1] == "valu":
+        valu(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else default_out)
+    elif sys.argv[1] == "counters":
         counters(sys.argv[2:])
     elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4],
