@@ -107,6 +107,9 @@ void pmap_index_destroy(pmap_index_t *idx);
 int pmap_reads_create(const char *bases, const uint64_t *offsets, uint32_t n_reads, uint32_t first_read_id,
                       pmap_reads_t **out);
 /* Re-runs only the device encode kernel of an uploaded batch (for measurement). */
+/* Replaces the batch held by `reads` with another one, reusing its device buffers. */
+int pmap_reads_update(pmap_reads_t *reads, const char *bases, const uint64_t *offsets, uint32_t n_reads,
+                      uint32_t first_read_id);
 int pmap_reads_repack(pmap_reads_t *reads);
 int pmap_reads_info(const pmap_reads_t *reads, uint32_t *n_reads, uint64_t *n_bases, uint64_t *device_bytes);
 void pmap_reads_destroy(pmap_reads_t *reads);
@@ -198,6 +201,25 @@ int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, uint32_t *si
                          uint32_t *first_rank);
 void pmap_result_destroy(pmap_result_t *res);
 
+/* ---------------------------------------------------------------- coverage */
+
+/* KmerNode coverage, the effect of pangenome::Graph::add_hits_to_kmergraphs
+ * (src/pangenome/pangraph.cpp:347-383; KmerNode::increment_covg,
+ * src/kmernode.cpp:42-49) kept as two device counters per index record (a
+ * MiniRecord is one kmer node of its PRG): hits with is_forward = 1 and 0.
+ * pmap_coverage_add adds, for every kept cluster c of a mapped batch (the
+ * order of pmap_result_clusters), weight[c] to the counter of each of its hits;
+ * weight[c] = 0 for a cluster that filter_clusters removed, otherwise the
+ * number of surviving clusters of the same (read, prg): the reference walks
+ * Node::reads, a multiset with one entry per add_node call, and counts every
+ * hit of the read on that node once per entry.  Record numbering is the
+ * caller's (pmap_index_create). */
+typedef struct pmap_coverage pmap_coverage_t;
+int pmap_coverage_create(const pmap_index_t *idx, pmap_coverage_t **out);
+int pmap_coverage_add(pmap_coverage_t *cov, const pmap_result_t *res, const uint32_t *weight);
+int pmap_coverage_fetch(const pmap_coverage_t *cov, uint32_t *forward, uint32_t *reverse);
+void pmap_coverage_destroy(pmap_coverage_t *cov);
+
 /* ---------------------------------------------------------------- host stages */
 
 /* clusterComp order (src/minihits.cpp:95-109) followed by filter_clusters
@@ -224,13 +246,18 @@ typedef struct {
     int clean;                  /* must be 0: the de Bruijn cleaning step (src/noise_filtering.cpp) is not part of this library */
     uint32_t max_covg;          /* default 300 */
     uint32_t batch_bases;       /* reads per device batch are cut at this many bases; 0 = default */
+    uint32_t flags;             /* PMAP_PG_* */
 } pmap_map_args_t;
+
+#define PMAP_PG_NO_HITS 1u      /* do not keep Read::hits (pmap_pangraph_hits returns nothing) */
+#define PMAP_PG_COVERAGE 2u     /* also accumulate the kmer node coverage on the device (pmap_pangraph_coverage) */
 
 /* Replaces pangraph_from_read_file (src/utils.cpp:379-455) with clean=false:
  * reads the file, applies the coverage / 10M-read stops, maps every batch on
  * the GPU, runs filter_clusters and performs the add_node sequence
  * (src/pangenome/pangraph.cpp:126-140) into a host summary.  *covg is the
- * function's return value. */
+ * function's return value.  A reader thread parses the file while the calling
+ * thread uploads and maps one batch and post-processes the batch before it. */
 int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx, const pmap_map_args_t *args,
                                  pmap_pangraph_t **out, uint32_t *covg);
 
@@ -254,6 +281,10 @@ int pmap_pangraph_hits(const pmap_pangraph_t *pg, uint32_t *read_id, uint32_t *p
 /* The add_node call sequence: (prg_id, read_id, cluster size, is_forward of first hit). */
 int pmap_pangraph_calls(const pmap_pangraph_t *pg, uint32_t *prg_id, uint32_t *read_id, uint32_t *size,
                         uint8_t *is_forward);
+/* With PMAP_PG_COVERAGE: the coverage every index record's kmer node has after
+ * add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383), forward and
+ * reverse hits, n_records entries each in the caller's record numbering. */
+int pmap_pangraph_coverage(const pmap_pangraph_t *pg, uint32_t *forward, uint32_t *reverse);
 void pmap_pangraph_destroy(pmap_pangraph_t *pg);
 
 #ifdef __cplusplus

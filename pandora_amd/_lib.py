@@ -44,7 +44,8 @@ class Counts(C.Structure):
 class MapArgs(C.Structure):
     _fields_ = [("w", C.c_uint32), ("k", C.c_uint32), ("max_diff", C.c_int32), ("e_rate", C.c_float),
                 ("min_cluster_size", C.c_uint32), ("genome_size", C.c_uint32), ("illumina", C.c_int),
-                ("clean", C.c_int), ("max_covg", C.c_uint32), ("batch_bases", C.c_uint32)]
+                ("clean", C.c_int), ("max_covg", C.c_uint32), ("batch_bases", C.c_uint32),
+                ("flags", C.c_uint32)]
 
 
 class PangraphInfo(C.Structure):
@@ -90,7 +91,13 @@ SIGNATURES = {
     "pmap_pangraph_reads": (C.c_int, [C.c_void_p, u32p, u64p, u32p, u8p]),
     "pmap_pangraph_hits": (C.c_int, [C.c_void_p, u32p, u32p, u32p, u32p, u8p]),
     "pmap_pangraph_calls": (C.c_int, [C.c_void_p, u32p, u32p, u32p, u8p]),
+    "pmap_pangraph_coverage": (C.c_int, [C.c_void_p, u32p, u32p]),
     "pmap_pangraph_destroy": (None, [C.c_void_p]),
+    "pmap_reads_update": (C.c_int, [C.c_void_p, C.c_char_p, u64p, C.c_uint32, C.c_uint32]),
+    "pmap_coverage_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pmap_coverage_add": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
+    "pmap_coverage_fetch": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "pmap_coverage_destroy": (None, [C.c_void_p]),
 }
 
 _lib = None

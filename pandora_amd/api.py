@@ -286,9 +286,17 @@ def read_fastaq(path):
 class Pangraph:
     """Summary of the pangenome::Graph that pangraph_from_read_file fills."""
 
-    def __init__(self, handle, covg):
+    def __init__(self, handle, covg, n_records=0):
         self._h = handle
         self.covg = covg
+        self._n_records = n_records
+
+    def coverage(self):
+        """KmerNode coverage after add_hits_to_kmergraphs, per index record: (forward, reverse)."""
+        fwd = np.zeros(self._n_records, np.uint32)
+        rev = np.zeros(self._n_records, np.uint32)
+        _check(_lib.load().pmap_pangraph_coverage(self._h, _p(fwd, u32p), _p(rev, u32p)))
+        return fwd, rev
 
     def info(self):
         i = _lib.PangraphInfo()
@@ -343,12 +351,13 @@ class Pangraph:
 
 
 def pangraph_from_read_file(filepath, index, w, k, max_diff, e_rate, min_cluster_size=10, genome_size=5000000,
-                            illumina=False, clean=False, max_covg=300, batch_bases=0):
-    """pangraph_from_read_file (include/utils.h:83-90): same arguments, same defaults."""
+                            illumina=False, clean=False, max_covg=300, batch_bases=0, keep_hits=True, coverage=False):
+    """pangraph_from_read_file (include/utils.h:83-90): same arguments, same defaults.  keep_hits=False
+    drops Read::hits; coverage=True also accumulates the kmer node coverage of add_hits_to_kmergraphs."""
     a = _lib.MapArgs(w, k, max_diff, e_rate, min_cluster_size, genome_size, int(illumina), int(clean), max_covg,
-                     batch_bases)
+                     batch_bases, (0 if keep_hits else 1) | (2 if coverage else 0))
     h = C.c_void_p()
     covg = C.c_uint32()
     _check(_lib.load().pmap_pangraph_from_read_file(str(filepath).encode(), index._h, C.byref(a), C.byref(h),
                                                     C.byref(covg)))
-    return Pangraph(h, covg.value)
+    return Pangraph(h, covg.value, index.info()["n_recs"])

@@ -49,6 +49,16 @@ extern "C" int pmap_init(int device) {
     return PMAP_OK;
 }
 
+void *pmap_pinned_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void pmap_pinned_free(void *p) {
+    if (p) (void) hipHostFree(p);
+}
+
 static int ensure_init() {
     if (g_ready) return PMAP_OK;
     return pmap_init(-1);
@@ -104,6 +114,8 @@ struct pmap_reads {
     DevBuf ascii, boff, woff, rlen, rflag;
     DevBuf words;    // uint2 per packed word: {16 bases, read index}
     DevBuf rmeta;    // uint2 per read: {first position in the padded stream, length or 0 if not sketchable}
+    std::vector<uint32_t> h_woff, h_rlen;   // host staging of the per-read tables (kept: the copies are asynchronous)
+    std::vector<uint64_t> h_boff;
     uint64_t device_bytes() const {
         return ascii.cap + boff.cap + woff.cap + rlen.cap + rflag.cap + words.cap + rmeta.cap;
     }
@@ -197,17 +209,21 @@ void pmap_index_release_device(pmap_index *idx) {
 // ---------------------------------------------------------------------------
 // reads
 
+// Uploads and encodes run on their own stream, so that a batch can be brought in while the kernels
+// of the batch before it run on the map stream.
+static hipStream_t g_upload = nullptr;
+
 static int launch_encode(pmap_reads *rd) {
-    HIP_TRY(hipMemsetAsync(rd->rflag.p, 0, sizeof(uint32_t) * (rd->n_reads + 1), g_stream));
+    HIP_TRY(hipMemsetAsync(rd->rflag.p, 0, sizeof(uint32_t) * (rd->n_reads + 1), g_upload));
     if (rd->n_words) {
-        hipLaunchKernelGGL(encode_kernel, dim3((rd->n_words + 255) / 256), dim3(256), 0, g_stream,
+        hipLaunchKernelGGL(encode_kernel, dim3((rd->n_words + 255) / 256), dim3(256), 0, g_upload,
                            rd->ascii.as<uint32_t>(), rd->boff.as<uint64_t>(), rd->woff.as<uint32_t>(),
                            rd->rlen.as<uint32_t>(), rd->n_reads, rd->n_words, rd->words.as<uint2>(),
                            rd->rflag.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     if (rd->n_reads) {
-        hipLaunchKernelGGL(read_meta_kernel, dim3((rd->n_reads + 255) / 256), dim3(256), 0, g_stream,
+        hipLaunchKernelGGL(read_meta_kernel, dim3((rd->n_reads + 255) / 256), dim3(256), 0, g_upload,
                            rd->woff.as<uint32_t>(), rd->rlen.as<uint32_t>(), rd->rflag.as<uint32_t>(), rd->n_reads,
                            rd->rmeta.as<uint2>());
         HIP_TRY(hipGetLastError());
@@ -215,16 +231,20 @@ static int launch_encode(pmap_reads *rd) {
     return PMAP_OK;
 }
 
-extern "C" int pmap_reads_create(const char *bases, const uint64_t *offsets, uint32_t n_reads,
-                                 uint32_t first_read_id, pmap_reads_t **out) {
-    int rc = ensure_init();
-    if (rc) return rc;
-    if (!offsets || !out || (n_reads && !bases && offsets[n_reads] != offsets[0]))
+// fills a reads object (new or reused: its buffers only grow) with a batch and waits for the upload
+static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets, uint32_t n_reads,
+                      uint32_t first_read_id) {
+    int rc;
+    if (!offsets || (n_reads && !bases && offsets[n_reads] != offsets[0]))
         return pmap_fail(PMAP_EINVAL, "null argument");
     if ((uint64_t) first_read_id + n_reads > 0xFFFFFFFEull)
         return pmap_fail(PMAP_ELIMIT, "read ids exceed 32 bits (src/minihit.cpp:18-19)");
-    std::vector<uint32_t> woff(n_reads + 1), rlen(n_reads + 1, 0);
-    std::vector<uint64_t> boff(n_reads + 1);
+    if (!g_upload) HIP_TRY(hipStreamCreateWithFlags(&g_upload, hipStreamNonBlocking));
+    std::vector<uint32_t> &woff = rd->h_woff, &rlen = rd->h_rlen;
+    std::vector<uint64_t> &boff = rd->h_boff;
+    woff.assign(n_reads + 1, 0);
+    rlen.assign(n_reads + 1, 0);
+    boff.assign(n_reads + 1, 0);
     uint64_t words = 0;
     const uint64_t base0 = offsets[0];
     for (uint32_t r = 0; r < n_reads; ++r) {
@@ -242,7 +262,6 @@ extern "C" int pmap_reads_create(const char *bases, const uint64_t *offsets, uin
     boff[n_reads] = offsets[n_reads] - base0;
     const uint64_t n_bases = offsets[n_reads] - base0;
 
-    pmap_reads *rd = new pmap_reads();
     rd->n_reads = n_reads;
     rd->first_read_id = first_read_id;
     rd->n_bases = n_bases;
@@ -250,44 +269,53 @@ extern "C" int pmap_reads_create(const char *bases, const uint64_t *offsets, uin
     rd->n_tiles = 0;   // the tiling depends on w: pmap_map computes it
     const size_t ascii_bytes = ((n_bases + 3) & ~3ull) + 64;
     const size_t word_slots = (size_t) words + 16;
-    auto fail = [&](int code) {
-        pmap_reads_destroy(rd);
-        return code;
-    };
     if ((rc = rd->ascii.ensure(ascii_bytes)) || (rc = rd->boff.ensure(sizeof(uint64_t) * (n_reads + 1))) ||
         (rc = rd->woff.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->rlen.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->rflag.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->words.ensure(sizeof(uint2) * word_slots)) ||
         (rc = rd->rmeta.ensure(sizeof(uint2) * (n_reads + 1))))
-        return fail(rc);
+        return rc;
     hipError_t e;
-    e = hipMemsetAsync((char *) rd->ascii.p + ((n_bases) & ~3ull), 0, ascii_bytes - (n_bases & ~3ull), g_stream);
-    if (e == hipSuccess) e = hipMemsetAsync(rd->words.p, 0, sizeof(uint2) * word_slots, g_stream);
-    if (e == hipSuccess) e = hipMemsetAsync(rd->rmeta.p, 0, sizeof(uint2) * (n_reads + 1), g_stream);
-    if (e == hipSuccess && n_bases) e = hipMemcpyAsync(rd->ascii.p, bases + base0, n_bases, hipMemcpyHostToDevice, g_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(rd->boff.p, boff.data(), sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice, g_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(rd->woff.p, woff.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(rd->rlen.p, rlen.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_stream);
-    if (e != hipSuccess) {
-        pmap_fail(PMAP_EHIP, std::string("read upload: ") + hipGetErrorString(e));
-        return fail(PMAP_EHIP);
-    }
-    if ((rc = launch_encode(rd))) return fail(rc);
-    e = hipStreamSynchronize(g_stream);
-    if (e != hipSuccess) {
-        pmap_fail(PMAP_EHIP, std::string("read encode: ") + hipGetErrorString(e));
-        return fail(PMAP_EHIP);
+    e = hipMemsetAsync((char *) rd->ascii.p + ((n_bases) & ~3ull), 0, ascii_bytes - (n_bases & ~3ull), g_upload);
+    // the words after the last one are read by the sketch kernel of the last tile: keep them empty
+    if (e == hipSuccess) e = hipMemsetAsync(rd->words.as<uint2>() + words, 0, sizeof(uint2) * 16, g_upload);
+    if (e == hipSuccess && n_bases) e = hipMemcpyAsync(rd->ascii.p, bases + base0, n_bases, hipMemcpyHostToDevice, g_upload);
+    if (e == hipSuccess) e = hipMemcpyAsync(rd->boff.p, boff.data(), sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
+    if (e == hipSuccess) e = hipMemcpyAsync(rd->woff.p, woff.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
+    if (e == hipSuccess) e = hipMemcpyAsync(rd->rlen.p, rlen.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
+    if (e != hipSuccess) return pmap_fail(PMAP_EHIP, std::string("read upload: ") + hipGetErrorString(e));
+    if ((rc = launch_encode(rd))) return rc;
+    e = hipStreamSynchronize(g_upload);
+    if (e != hipSuccess) return pmap_fail(PMAP_EHIP, std::string("read encode: ") + hipGetErrorString(e));
+    return PMAP_OK;
+}
+
+extern "C" int pmap_reads_create(const char *bases, const uint64_t *offsets, uint32_t n_reads,
+                                 uint32_t first_read_id, pmap_reads_t **out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!out) return pmap_fail(PMAP_EINVAL, "null argument");
+    pmap_reads *rd = new pmap_reads();
+    if ((rc = reads_fill(rd, bases, offsets, n_reads, first_read_id))) {
+        pmap_reads_destroy(rd);
+        return rc;
     }
     *out = rd;
     return PMAP_OK;
+}
+
+extern "C" int pmap_reads_update(pmap_reads_t *rd, const char *bases, const uint64_t *offsets, uint32_t n_reads,
+                                 uint32_t first_read_id) {
+    if (!rd) return pmap_fail(PMAP_EINVAL, "null argument");
+    return reads_fill(rd, bases, offsets, n_reads, first_read_id);
 }
 
 extern "C" int pmap_reads_repack(pmap_reads_t *rd) {
     if (!rd) return pmap_fail(PMAP_EINVAL, "null argument");
     int rc = launch_encode(rd);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(g_upload));
     return PMAP_OK;
 }
 
@@ -780,6 +808,68 @@ extern "C" int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, u
         if (first_rank) first_rank[i] = r[6];
     }
     return PMAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// coverage
+
+struct pmap_coverage {
+    uint32_t n_recs = 0;
+    DevBuf covg, weight;
+};
+
+extern "C" int pmap_coverage_create(const pmap_index_t *idx, pmap_coverage_t **out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!idx || !out) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (idx->n_recs >= 0x7FFFFFFFull) return pmap_fail(PMAP_ELIMIT, "too many records for 32-bit record indices");
+    pmap_coverage *cov = new pmap_coverage();
+    cov->n_recs = (uint32_t) idx->n_recs;
+    const size_t bytes = sizeof(uint32_t) * 2 * ((size_t) cov->n_recs + 1);
+    if ((rc = cov->covg.ensure(bytes))) {
+        delete cov;
+        return rc;
+    }
+    HIP_TRY(hipMemsetAsync(cov->covg.p, 0, bytes, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    *out = cov;
+    return PMAP_OK;
+}
+
+extern "C" int pmap_coverage_add(pmap_coverage_t *cov, const pmap_result_t *res, const uint32_t *weight) {
+    if (!cov || !res) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc0 = settled(res)) return rc0;
+    const uint32_t n = (uint32_t) res->counts.n_clusters;
+    if (n == 0) return PMAP_OK;
+    if (!weight) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (res->p_idx == nullptr || res->p_idx->n_recs != cov->n_recs)
+        return pmap_fail(PMAP_EINVAL, "the result was mapped against another index than the coverage belongs to");
+    int rc;
+    if ((rc = cov->weight.ensure(sizeof(uint32_t) * n))) return rc;
+    // blocking copy: the caller's array may change as soon as this call returns
+    HIP_TRY(hipMemcpy(cov->weight.p, weight, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(coverage_kernel, dim3((n + 3) / 4), dim3(256), 0, g_stream, res->k_rows.as<uint32_t>(),
+                       cov->weight.as<uint32_t>(), n, res->s_rec.as<uint32_t>(), cov->n_recs, cov->covg.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    // the weights may be overwritten by the next call: wait (the kernel is short)
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PMAP_OK;
+}
+
+extern "C" int pmap_coverage_fetch(const pmap_coverage_t *cov, uint32_t *forward, uint32_t *reverse) {
+    if (!cov) return pmap_fail(PMAP_EINVAL, "null argument");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    const size_t b = sizeof(uint32_t) * cov->n_recs;
+    if (forward && b) HIP_TRY(hipMemcpy(forward, cov->covg.p, b, hipMemcpyDeviceToHost));
+    if (reverse && b) HIP_TRY(hipMemcpy(reverse, cov->covg.as<uint32_t>() + cov->n_recs, b, hipMemcpyDeviceToHost));
+    return PMAP_OK;
+}
+
+extern "C" void pmap_coverage_destroy(pmap_coverage_t *cov) {
+    if (!cov) return;
+    cov->covg.release();
+    cov->weight.release();
+    delete cov;
 }
 
 extern "C" void pmap_result_destroy(pmap_result_t *res) {

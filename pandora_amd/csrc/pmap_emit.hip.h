@@ -175,4 +175,21 @@ __global__ __launch_bounds__(256) void compact_minimizers_kernel(const uint32_t 
     }
 }
 
+// KmerNode coverage (pangenome::Graph::add_hits_to_kmergraphs, src/pangenome/pangraph.cpp:347-383,
+// KmerNode::increment_covg, src/kmernode.cpp:42-49): one wavefront per kept cluster adds the
+// cluster's weight to the counter of every hit's record, forward hits in covg[0, n_recs), reverse
+// hits in covg[n_recs, 2 n_recs).  weight 0 = the cluster did not survive filter_clusters.
+__global__ __launch_bounds__(256) void coverage_kernel(const uint32_t *__restrict__ k_rows,
+                                                       const uint32_t *__restrict__ weight, uint32_t n_kept,
+                                                       const uint32_t *__restrict__ s_rec, uint32_t n_recs,
+                                                       uint32_t *__restrict__ covg) {
+    const uint32_t lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_kept) return;
+    const uint32_t wgt = weight[c];
+    if (wgt == 0) return;
+    const uint4 row = *(const uint4 *) (k_rows + (uint64_t) c * 8);   // first hit, size, read, prg << 1 | !forward
+    uint32_t *dst = covg + ((row.w & 1u) ? n_recs : 0u);
+    for (uint32_t i = lane; i < row.y; i += 64) atomicAdd(&dst[s_rec[row.x + i]], wgt);
+}
+
 #endif

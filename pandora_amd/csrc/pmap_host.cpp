@@ -6,12 +6,16 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pmap_internal.h"
@@ -62,76 +66,115 @@ extern "C" int pmap_filter_clusters(uint64_t n, const uint32_t *read_id, const u
 
 namespace {
 
-// std::istream semantics that FastaqHandler relies on, over a memory buffer
+// std::istream semantics that FastaqHandler relies on, over a plain or gzip file read in chunks
+// (gzread is transparent for uncompressed files)
 struct LineStream {
-    const std::string &buf;
-    size_t pos = 0;
-    bool eofbit = false;
-    explicit LineStream(const std::string &b) : buf(b) {}
-    bool at_eof() {   // instream.peek() == EOF (src/fastaq_handler.cpp:38-41)
-        if (eofbit || pos >= buf.size()) { eofbit = true; return true; }
-        return false;
-    }
-    // getline(...).good(): false when the data ended before a newline was seen
-    bool getline(std::string *line) {
-        line->clear();
-        if (eofbit || pos >= buf.size()) { eofbit = true; return false; }
-        size_t nl = buf.find('\n', pos);
-        if (nl == std::string::npos) {
-            line->assign(buf, pos, std::string::npos);
-            pos = buf.size();
-            eofbit = true;
-            return false;
-        }
-        line->assign(buf, pos, nl - pos);
-        pos = nl + 1;
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eofbit = false, drained = false, io_error = false;
+    bool open(const char *path) {
+        f = gzopen(path, "rb");
+        if (!f) return false;
+        gzbuffer(f, 1 << 20);
+        buf.resize(8 << 20);
         return true;
     }
-};
-
-struct FastaqReader {
-    std::string data;
-    LineStream in;
-    std::string line, name, read;
-    explicit FastaqReader(std::string d) : data(std::move(d)), in(data) {}
-    bool eof() { return in.at_eof(); }
-    void get_next() {   // src/fastaq_handler.cpp:43-71
-        if (!line.empty() && (line[0] == '>' || line[0] == '@')) {
-            name = line.substr(1);
-            read.clear();
+    ~LineStream() { if (f) gzclose(f); }
+    // moves the unread bytes to the front and reads more; false when nothing was added
+    bool fill() {
+        if (drained) return false;
+        if (pos > 0) {
+            memmove(buf.data(), buf.data() + pos, end - pos);
+            end -= pos;
+            pos = 0;
         }
-        while (in.getline(&line)) {
-            if (!line.empty() && line[0] == '+') {
-                in.getline(&line);   // quality line
-            } else if (line.empty() || line[0] == '>' || line[0] == '@') {
-                if (!read.empty() || line.empty()) return;
-                name = line.substr(1);
-                read.clear();
-            } else {
-                read += line;
+        if (end == buf.size()) buf.resize(buf.size() * 2);   // one line longer than the buffer
+        const int n = gzread(f, buf.data() + end, (unsigned) std::min<size_t>(buf.size() - end, 1u << 30));
+        if (n < 0) io_error = true;
+        if (n <= 0) { drained = true; return false; }
+        end += (size_t) n;
+        return true;
+    }
+    bool at_eof() {   // instream.peek() == EOF (src/fastaq_handler.cpp:38-41)
+        if (eofbit) return true;
+        if (pos < end || fill()) return false;
+        eofbit = true;
+        return true;
+    }
+    // getline(...).good(): false when the data ended before a newline was seen.  *line points into
+    // the buffer and is valid until the next call.
+    bool getline(const char **line, size_t *len) {
+        *line = buf.data();
+        *len = 0;
+        if (eofbit) return false;
+        if (pos >= end && !fill()) { eofbit = true; return false; }
+        size_t scanned = 0;
+        for (;;) {
+            const char *nl = (const char *) memchr(buf.data() + pos + scanned, '\n', end - pos - scanned);
+            if (nl) {
+                *line = buf.data() + pos;
+                *len = (size_t) (nl - (buf.data() + pos));
+                pos += *len + 1;
+                return true;
+            }
+            scanned = end - pos;
+            if (!fill()) {   // unterminated last line
+                *line = buf.data() + pos;
+                *len = end - pos;
+                pos = end;
+                eofbit = true;
+                return false;
             }
         }
     }
 };
 
-bool load_file(const char *path, std::string *out) {
-    gzFile f = gzopen(path, "rb");   // transparent for uncompressed files
-    if (!f) return false;
-    std::vector<char> chunk(1 << 20);
-    int n;
-    while ((n = gzread(f, chunk.data(), (unsigned) chunk.size())) > 0) out->append(chunk.data(), (size_t) n);
-    gzclose(f);
-    return n == 0;
-}
+struct FastaqReader {
+    LineStream in;
+    // the last line read: only its first character and its emptiness matter to get_next
+    bool line_empty = true;
+    char line_first = 0;
+    std::string pending_name;     // the header line that ended the record before
+    std::string name, read;
+    bool open(const char *path) { return in.open(path); }
+    bool eof() { return in.at_eof(); }
+    void get_next() {   // src/fastaq_handler.cpp:43-71
+        if (!line_empty && (line_first == '>' || line_first == '@')) {
+            name = pending_name;
+            read.clear();
+        }
+        const char *l;
+        size_t n;
+        for (;;) {
+            const bool good = in.getline(&l, &n);
+            line_empty = n == 0;
+            line_first = n ? l[0] : 0;
+            if (!line_empty && (line_first == '>' || line_first == '@')) pending_name.assign(l + 1, n - 1);
+            if (!good) return;
+            if (!line_empty && line_first == '+') {
+                in.getline(&l, &n);   // quality line
+                line_empty = n == 0;
+                line_first = n ? l[0] : 0;
+                if (!line_empty && (line_first == '>' || line_first == '@')) pending_name.assign(l + 1, n - 1);
+            } else if (line_empty || line_first == '>' || line_first == '@') {
+                if (!read.empty() || line_empty) return;
+                name = pending_name;
+                read.clear();
+            } else {
+                read.append(l, n);
+            }
+        }
+    }
+};
 
 }  // namespace
 
 extern "C" int pmap_read_fastaq(const char *path, char **bases, uint64_t **offsets, uint32_t *n_reads,
                                 char **names, uint64_t **name_offsets) {
-    std::string data;
-    if (!load_file(path, &data))
+    FastaqReader fh;
+    if (!fh.open(path))
         return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + path);   // src/fastaq_handler.cpp:18-21
-    FastaqReader fh(std::move(data));
     std::string all, allnames;
     std::vector<uint64_t> off{0}, noff{0};
     while (!fh.eof()) {
@@ -186,6 +229,7 @@ struct pmap_pangraph {
     std::vector<uint32_t> call_prg, call_read, call_size;
     std::vector<uint8_t> call_fwd;
     bool hits_sorted = false;
+    pmap_coverage_t *cov = nullptr;   // device coverage counters (PMAP_PG_COVERAGE)
 };
 
 // pangenome::Graph::add_node (src/pangenome/pangraph.cpp:126-140) with get_node (:59-76) and
@@ -218,82 +262,108 @@ static void pg_sort_hits(pmap_pangraph *pg) {
     pg->hits_sorted = true;
 }
 
-// one device batch -> filter_clusters -> add_node calls
-static int map_batch(const pmap_index_t *idx, const pmap_params_t *prm, const std::string &bases,
-                     const std::vector<uint64_t> &offsets, uint32_t first_id, pmap_result_t **res,
-                     pmap_pangraph *pg) {
-    const uint32_t n = (uint32_t) (offsets.size() - 1);
-    if (n == 0) return PMAP_OK;
-    pmap_reads_t *rd = nullptr;
-    int rc = pmap_reads_create(bases.data(), offsets.data(), n, first_id, &rd);
-    if (rc) return rc;
-    rc = pmap_map(idx, rd, prm, res);
-    pmap_reads_destroy(rd);
-    if (rc) return rc;
-    pmap_counts_t cn;
-    pmap_result_counts(*res, &cn);
-    const size_t nc = cn.n_clusters, nh = cn.n_hits;
-    if (nc == 0) return PMAP_OK;
-    std::vector<uint64_t> begin(nc), order(nc);
-    std::vector<uint32_t> size(nc), rid(nc), prg(nc), fpos(nc), lpos(nc), frank(nc);
-    std::vector<uint8_t> fwd(nc), alive(nc);
-    if ((rc = pmap_result_clusters(*res, begin.data(), size.data(), rid.data(), prg.data(), fwd.data(), fpos.data(),
-                                   lpos.data(), frank.data())))
-        return rc;
-    if ((rc = pmap_filter_clusters(nc, rid.data(), fpos.data(), size.data(), prg.data(), frank.data(), fwd.data(),
-                                   lpos.data(), order.data(), alive.data())))
-        return rc;
-    std::vector<uint32_t> hpos(nh), hrec(nh);
-    if ((rc = pmap_result_hits(*res, 1, nullptr, hpos.data(), nullptr, hrec.data(), nullptr))) return rc;
-    for (size_t j = 0; j < nc; ++j) {
-        if (!alive[j]) continue;
-        const uint64_t c = order[j];
-        pg_add_node(pg, prg[c], rid[c], size[c], fwd[c] != 0);
-        for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
-            pg->hits.push_back(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
-    }
-    pg->hits_sorted = false;
-    return PMAP_OK;
-}
+// ---------------------------------------------------------------------------
+// pangraph_from_read_file as a three-stage pipeline: a reader thread parses the file into batches
+// (pinned host memory), the calling thread uploads batch i+1 and enqueues its kernels while the GPU
+// maps batch i, then finishes batch i-1 on the host (filter_clusters, add_node, coverage).
 
-extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx,
-                                            const pmap_map_args_t *a, pmap_pangraph_t **out, uint32_t *covg_out) {
-    if (!reads_path || !idx || !a || !out) return pmap_fail(PMAP_EINVAL, "null argument");
-    if (a->clean) return pmap_fail(PMAP_EINVAL, "clean=true (de Bruijn cleaning of the pangraph) is outside this library");
-    if (a->w == 0 || a->genome_size == 0) return pmap_fail(PMAP_EINVAL, "w and genome_size must be positive");
-    std::string data;
-    if (!load_file(reads_path, &data))
-        return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + reads_path);
-    FastaqReader fh(std::move(data));
+namespace {
 
+struct Batch {
+    char *data = nullptr;          // pinned
+    size_t size = 0, cap = 0;
+    std::vector<uint64_t> offsets{0};
+    uint32_t first_id = 0;
     pmap_params_t prm;
-    memset(&prm, 0, sizeof(prm));
-    prm.w = a->w;
-    prm.k = a->k;
-    prm.max_diff = a->max_diff;
-    prm.fraction = pmap_fraction(a->e_rate, a->k);                 // src/utils.cpp:394
-    prm.min_cluster_size = a->min_cluster_size;
-    prm.expected_kmers = std::numeric_limits<uint32_t>::max();     // :395
-    const uint64_t batch_bases = a->batch_bases ? a->batch_bases : (256ull << 20);
+    void reset(uint32_t first) {
+        size = 0;
+        offsets.assign(1, 0);
+        first_id = first;
+    }
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        size_t ncap = std::max(want, cap + cap / 2);
+        char *p = (char *) pmap_pinned_alloc(ncap);
+        if (!p) return false;
+        if (size) memcpy(p, data, size);
+        if (data) pmap_pinned_free(data);
+        data = p;
+        cap = ncap;
+        return true;
+    }
+    void append(const std::string &seq) {
+        memcpy(data + size, seq.data(), seq.size());
+        size += seq.size();
+        offsets.push_back(size);
+    }
+};
 
-    pmap_pangraph *pg = new pmap_pangraph();
-    pmap_result_t *res = nullptr;
+// bounded hand-over of batches between the reader thread and the mapping thread
+struct BatchQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Batch *> ready, free_list;
+    bool done = false;      // the reader has pushed its last batch
+    bool abort = false;     // the consumer gave up: the reader must stop
+    Batch *get_free() {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return abort || !free_list.empty(); });
+        if (abort) return nullptr;
+        Batch *b = free_list.front();
+        free_list.pop_front();
+        return b;
+    }
+    void put_free(Batch *b) {
+        { std::lock_guard<std::mutex> l(m); free_list.push_back(b); }
+        cv.notify_all();
+    }
+    void put_ready(Batch *b) {
+        { std::lock_guard<std::mutex> l(m); ready.push_back(b); }
+        cv.notify_all();
+    }
+    Batch *get_ready() {    // nullptr: no more batches
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return done || !ready.empty(); });
+        if (ready.empty()) return nullptr;
+        Batch *b = ready.front();
+        ready.pop_front();
+        return b;
+    }
+    void finish() {
+        { std::lock_guard<std::mutex> l(m); done = true; }
+        cv.notify_all();
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> l(m); abort = true; }
+        cv.notify_all();
+    }
+};
+
+struct ReaderResult {
+    uint64_t covg = 0;
+    int rc = PMAP_OK;
+    std::string error;
+};
+
+// The read loop of pangraph_from_read_file (src/utils.cpp:397-440) up to the point where a read is
+// handed to the sketch: ids, coverage stop, 10M-read stop, Illumina expected k-mer count.
+void reader_thread(FastaqReader *fh, const pmap_map_args_t *a, pmap_params_t prm, uint64_t batch_bases,
+                   BatchQueue *q, ReaderResult *out) {
     uint64_t covg = 0;
     uint32_t id = 0;
-    std::string bases;
-    std::vector<uint64_t> offsets{0};
-    uint32_t batch_first = 0;
-    int rc = PMAP_OK;
-    auto flush = [&]() {
-        int r = map_batch(idx, &prm, bases, offsets, batch_first, &res, pg);
-        bases.clear();
-        offsets.assign(1, 0);
-        batch_first = id;
-        return r;
+    Batch *b = q->get_free();
+    if (b) b->reset(0);
+    auto flush = [&]() -> bool {      // hands the batch over and takes an empty one
+        b->prm = prm;
+        q->put_ready(b);
+        b = q->get_free();
+        if (!b) return false;
+        b->reset(id);
+        return true;
     };
-    while (!fh.eof()) {
-        fh.get_next();
-        const std::string &seq = fh.read;
+    while (b && !fh->eof()) {
+        fh->get_next();
+        const std::string &seq = fh->read;
         // Seq::initialize -> the sketch is non-empty iff the read has a full window and only ACGT letters
         bool sketched = seq.size() + 1 >= (uint64_t) a->w + a->k;
         if (sketched)
@@ -304,30 +374,155 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
         if (sketched) {
             covg += seq.size();                                         // :404
             if (covg / a->genome_size > a->max_covg) break;             // :405-408
-        } else {
-            // consumes an id (:409-412); travels in the batch so ids stay consecutive, yields nothing
-            bases += seq;
-            offsets.push_back(bases.size());
-            id++;
-            continue;
+            if (a->illumina && prm.expected_kmers == std::numeric_limits<uint32_t>::max()) {
+                // the threshold changes from here on: reads before this one had no sketch, so no hits
+                prm.expected_kmers = (uint32_t) (seq.size() * 2 / a->w);    // :413-416
+            }
         }
-        if (a->illumina && prm.expected_kmers == std::numeric_limits<uint32_t>::max()) {
-            // the threshold changes from here on: reads before this one had no sketch, so no hits
-            prm.expected_kmers = (uint32_t) (seq.size() * 2 / a->w);    // :413-416
+        // a read without a sketch consumes an id too (:409-412): it travels in the batch so that ids stay
+        // consecutive, and yields nothing
+        if (b->size + seq.size() > b->cap && b->size > 0 && !flush()) break;
+        if (!b->reserve(b->size + seq.size() + 64)) {
+            out->rc = PMAP_EHIP;
+            out->error = "out of pinned host memory for a read batch";
+            break;
         }
-        bases += seq;
-        offsets.push_back(bases.size());
+        b->append(seq);
         id++;
-        if (id > 10000000) break;                                       // :420-423
-        if (bases.size() >= batch_bases && (rc = flush())) break;
+        if (sketched && id > 10000000) break;                           // :420-423
+        if (b->size >= batch_bases && !flush()) break;
     }
-    if (rc == PMAP_OK) rc = flush();
-    pmap_result_destroy(res);
-    if (rc) {
+    if (fh->in.io_error && out->rc == PMAP_OK) {
+        out->rc = PMAP_EIO;
+        out->error = "error while reading the fastaq file";
+    }
+    if (b) {
+        b->prm = prm;
+        q->put_ready(b);
+    }
+    out->covg = covg;
+    q->finish();
+}
+
+// host side of one mapped batch: filter_clusters -> add_node calls (+ Read::hits, + coverage)
+int finish_batch(const pmap_index_t *idx, pmap_result_t *res, pmap_pangraph *pg, bool keep_hits,
+                 pmap_coverage_t *cov) {
+    pmap_counts_t cn;
+    int rc = pmap_result_counts(res, &cn);   // waits for the batch
+    if (rc) return rc;
+    const size_t nc = cn.n_clusters, nh = cn.n_hits;
+    if (nc == 0) return PMAP_OK;
+    std::vector<uint64_t> begin(nc), order(nc);
+    std::vector<uint32_t> size(nc), rid(nc), prg(nc), fpos(nc), lpos(nc), frank(nc);
+    std::vector<uint8_t> fwd(nc), alive(nc);
+    if ((rc = pmap_result_clusters(res, begin.data(), size.data(), rid.data(), prg.data(), fwd.data(), fpos.data(),
+                                   lpos.data(), frank.data())))
+        return rc;
+    if ((rc = pmap_filter_clusters(nc, rid.data(), fpos.data(), size.data(), prg.data(), frank.data(), fwd.data(),
+                                   lpos.data(), order.data(), alive.data())))
+        return rc;
+    std::vector<uint32_t> hpos, hrec;
+    if (keep_hits) {
+        hpos.resize(nh);
+        hrec.resize(nh);
+        if ((rc = pmap_result_hits(res, 1, nullptr, hpos.data(), nullptr, hrec.data(), nullptr))) return rc;
+    }
+    for (size_t j = 0; j < nc; ++j) {
+        if (!alive[j]) continue;
+        const uint64_t c = order[j];
+        pg_add_node(pg, prg[c], rid[c], size[c], fwd[c] != 0);
+        if (keep_hits)
+            for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
+                pg->hits.push_back(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
+    }
+    pg->hits_sorted = false;
+    if (cov) {
+        // add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383) walks Node::reads, a multiset that
+        // holds a read once per add_node call, and for each entry every hit of the read on that node: a
+        // hit counts as many times as its (read, prg) has surviving clusters
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> calls;
+        for (size_t j = 0; j < nc; ++j)
+            if (alive[j]) calls[{rid[order[j]], prg[order[j]]}] += 1;
+        std::vector<uint32_t> weight(nc, 0);
+        for (size_t j = 0; j < nc; ++j)
+            if (alive[j]) weight[order[j]] = calls[{rid[order[j]], prg[order[j]]}];
+        if ((rc = pmap_coverage_add(cov, res, weight.data()))) return rc;
+    }
+    return PMAP_OK;
+}
+
+}  // namespace
+
+extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx,
+                                            const pmap_map_args_t *a, pmap_pangraph_t **out, uint32_t *covg_out) {
+    if (!reads_path || !idx || !a || !out) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (a->clean) return pmap_fail(PMAP_EINVAL, "clean=true (de Bruijn cleaning of the pangraph) is outside this library");
+    if (a->w == 0 || a->genome_size == 0) return pmap_fail(PMAP_EINVAL, "w and genome_size must be positive");
+    int rc = pmap_init(-1);
+    if (rc) return rc;
+    FastaqReader fh;
+    if (!fh.open(reads_path))
+        return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + reads_path);
+
+    pmap_params_t prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.w = a->w;
+    prm.k = a->k;
+    prm.max_diff = a->max_diff;
+    prm.fraction = pmap_fraction(a->e_rate, a->k);                 // src/utils.cpp:394
+    prm.min_cluster_size = a->min_cluster_size;
+    prm.expected_kmers = std::numeric_limits<uint32_t>::max();     // :395
+    const uint64_t batch_bases = a->batch_bases ? a->batch_bases : (256ull << 20);
+    const bool keep_hits = !(a->flags & PMAP_PG_NO_HITS);
+
+    pmap_pangraph *pg = new pmap_pangraph();
+    if ((a->flags & PMAP_PG_COVERAGE) && (rc = pmap_coverage_create(idx, &pg->cov))) {
         delete pg;
         return rc;
     }
-    if (covg_out) *covg_out = (uint32_t) (covg / a->genome_size);      // :442, 454
+    Batch batches[3];
+    BatchQueue q;
+    for (Batch &b : batches) {
+        if (!b.reserve(batch_bases + (1u << 20))) {
+            for (Batch &x : batches) if (x.data) pmap_pinned_free(x.data);
+            delete pg;
+            return pmap_fail(PMAP_EHIP, "out of pinned host memory for the read batches");
+        }
+        q.free_list.push_back(&b);
+    }
+    ReaderResult rr;
+    std::thread reader(reader_thread, &fh, a, prm, batch_bases, &q, &rr);
+
+    pmap_reads_t *rds[2] = {nullptr, nullptr};
+    pmap_result_t *ress[2] = {nullptr, nullptr};
+    int slot = 0, pending = -1;
+    while (Batch *b = q.get_ready()) {
+        const uint32_t n = (uint32_t) (b->offsets.size() - 1);
+        if (n == 0) { q.put_free(b); continue; }
+        if (!rds[slot]) rc = pmap_reads_create(b->data, b->offsets.data(), n, b->first_id, &rds[slot]);
+        else rc = pmap_reads_update(rds[slot], b->data, b->offsets.data(), n, b->first_id);
+        const pmap_params_t bprm = b->prm;
+        q.put_free(b);                                             // the upload has finished
+        if (rc == PMAP_OK) rc = pmap_map_async(idx, rds[slot], &bprm, &ress[slot]);
+        if (rc == PMAP_OK && pending >= 0) rc = finish_batch(idx, ress[pending], pg, keep_hits, pg->cov);
+        if (rc) break;
+        pending = slot;
+        slot ^= 1;
+    }
+    if (rc == PMAP_OK && pending >= 0) rc = finish_batch(idx, ress[pending], pg, keep_hits, pg->cov);
+    q.stop();
+    reader.join();
+    if (rc == PMAP_OK && rr.rc) rc = pmap_fail(rr.rc, rr.error);
+    for (int i = 0; i < 2; ++i) {
+        pmap_result_destroy(ress[i]);
+        pmap_reads_destroy(rds[i]);
+    }
+    for (Batch &b : batches) if (b.data) pmap_pinned_free(b.data);
+    if (rc) {
+        pmap_pangraph_destroy(pg);
+        return rc;
+    }
+    if (covg_out) *covg_out = (uint32_t) (rr.covg / a->genome_size);      // :442, 454
     *out = pg;
     return PMAP_OK;
 }
@@ -400,4 +595,15 @@ extern "C" int pmap_pangraph_calls(const pmap_pangraph_t *pg, uint32_t *prg_id, 
     return PMAP_OK;
 }
 
-extern "C" void pmap_pangraph_destroy(pmap_pangraph_t *pg) { delete pg; }
+// KmerNode coverage after add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383), per index record
+extern "C" int pmap_pangraph_coverage(const pmap_pangraph_t *pg, uint32_t *forward, uint32_t *reverse) {
+    if (!pg) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (!pg->cov) return pmap_fail(PMAP_EINVAL, "the pangraph was built without PMAP_PG_COVERAGE");
+    return pmap_coverage_fetch(pg->cov, forward, reverse);
+}
+
+extern "C" void pmap_pangraph_destroy(pmap_pangraph_t *pg) {
+    if (!pg) return;
+    pmap_coverage_destroy(pg->cov);
+    delete pg;
+}

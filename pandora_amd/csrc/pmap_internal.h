@@ -68,6 +68,10 @@ struct pmap_index {
     bool thr_valid = false;
 };
 
+// pinned host memory (hipHostMalloc), nullptr on failure
+void *pmap_pinned_alloc(size_t bytes);
+void pmap_pinned_free(void *p);
+
 void pmap_set_error(const std::string &msg);
 int pmap_fail(int code, const std::string &msg);
 

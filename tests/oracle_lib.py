@@ -262,3 +262,22 @@ def fastaq_iterate(buf):
     cbf = _CB(cb)
     lib().orc_fastaq_iterate(buf, len(buf), C.cast(cbf, C.c_void_p), None)
     return out
+
+
+def oracle_coverage(res, n_records):
+    """KmerNode coverage after pangenome::Graph::add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383)
+    from an oracle_map result: Node::reads is a multiset with one entry per add_node call (:80-89), and for
+    every entry each hit of Read::hits[prg] (the union of the read's surviving clusters on that prg,
+    src/pangenome/panread.cpp:21-28) increments its kmer node's counter of the hit's direction
+    (src/kmernode.cpp:42-49).  Returns (forward, reverse) counters per index record."""
+    alive = res["cl_alive"].astype(bool)
+    calls = {}
+    for r, p in zip(res["cl_read"][alive], res["cl_prg"][alive]):
+        calls[(int(r), int(p))] = calls.get((int(r), int(p)), 0) + 1
+    fwd = np.zeros(n_records, np.uint32)
+    rev = np.zeros(n_records, np.uint32)
+    for b, s, r, p, f in zip(res["cl_begin"][alive], res["cl_size"][alive], res["cl_read"][alive],
+                             res["cl_prg"][alive], res["cl_fwd"][alive]):
+        recs = res["hit_rec"][int(b):int(b) + int(s)]
+        np.add.at(fwd if f else rev, recs, calls[(int(r), int(p))])
+    return fwd, rev

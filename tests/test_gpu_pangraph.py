@@ -98,10 +98,25 @@ def test_file_parity_nanopore(gpu, tmp_path):
     idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
                            si.iv_start, si.iv_len, si.min_path_length)
     res, covg, _ = _expected_from_oracle(si, p.read_bytes(), 14, 15, 250, 0.11, 10, 5000, False, 300)
+    want_fwd, want_rev = O.oracle_coverage(res, len(si.rec_prg))
+    assert want_fwd.sum() + want_rev.sum() > 1000 and want_fwd.max() > 1
     for batch in (0, 20000, 3000):                    # batch size must not change anything
-        pg = api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000, False, False, 300, batch_bases=batch)
+        pg = api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000, False, False, 300, batch_bases=batch,
+                                         coverage=True)
         n = _check_pangraph(pg, res, covg)
         assert n > 20
+        got_fwd, got_rev = pg.coverage()
+        np.testing.assert_array_equal(got_fwd, want_fwd)
+        np.testing.assert_array_equal(got_rev, want_rev)
+    # without Read::hits: same graph, same coverage, no hits kept
+    pg = api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000, False, False, 300, batch_bases=7000,
+                                     keep_hits=False, coverage=True)
+    assert pg.info()["n_hits"] == 0 and len(pg.calls()["prg"]) == n
+    got_fwd, got_rev = pg.coverage()
+    np.testing.assert_array_equal(got_fwd, want_fwd)
+    np.testing.assert_array_equal(got_rev, want_rev)
+    with pytest.raises(api.PmapError):
+        api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000).coverage()     # built without coverage
 
 
 def test_file_parity_coverage_stop_and_illumina(gpu, tmp_path):
@@ -116,11 +131,50 @@ def test_file_parity_coverage_stop_and_illumina(gpu, tmp_path):
                            si.iv_start, si.iv_len, si.min_path_length)
     # genome_size 1000, max_covg 20: stops after ~21 kb of sketched reads
     res, covg, _ = _expected_from_oracle(si, p.read_bytes(), 14, 15, 31, 0.001, 2, 1000, True, 20)
-    pg = api.pangraph_from_read_file(p, idx, 14, 15, 31, 0.001, 2, 1000, True, False, 20, batch_bases=5000)
+    pg = api.pangraph_from_read_file(p, idx, 14, 15, 31, 0.001, 2, 1000, True, False, 20, batch_bases=5000,
+                                     coverage=True)
     n = _check_pangraph(pg, res, covg)
+    want_fwd, want_rev = O.oracle_coverage(res, len(si.rec_prg))
+    got_fwd, got_rev = pg.coverage()
+    np.testing.assert_array_equal(got_fwd, want_fwd)
+    np.testing.assert_array_equal(got_rev, want_rev)
     assert covg == 21 and 0 < n and max(pg.reads()) < 200
     with pytest.raises(api.PmapError):
         api.pangraph_from_read_file(p, idx, 14, 15, 31, 0.001, 2, 1000, True, True, 20)      # clean=true
     with pytest.raises(api.PmapError) as e:
         api.pangraph_from_read_file(tmp_path / "missing.fa", idx, 14, 15, 31, 0.001)
     assert e.value.code == 3
+
+
+def test_gzip_and_repeated_clusters_coverage(gpu, tmp_path):
+    """A gzip file, and reads that cross the same locus twice (two surviving clusters on one prg): every hit
+    of such a read counts twice in the kmer node coverage, as in add_hits_to_kmergraphs."""
+    import gzip
+    rng = np.random.default_rng(23)
+    loci = synth.make_loci(6, rng)
+    si = synth.build_index(loci, 14, 15)
+    spacer = lambda n: bytes(synth.random_dna(n, rng))
+    reads = []
+    for i in range(12):
+        l = bytes(loci[i % 6])
+        reads.append(spacer(300) + l + spacer(800) + l + spacer(200))        # the same locus twice
+        reads.append(spacer(100) + l + spacer(50) + bytes(synth.revcomp(loci[(i + 1) % 6])))
+    bases, off = O.pack_reads(reads)
+    p = tmp_path / "twice.fq.gz"
+    plain = tmp_path / "twice.fq"
+    _write_fastq(plain, bases, off, rng, blank_tail=False)
+    with gzip.open(p, "wb") as f:
+        f.write(plain.read_bytes())
+    idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                           si.iv_start, si.iv_len, si.min_path_length)
+    res, covg, _ = _expected_from_oracle(si, plain.read_bytes(), 14, 15, 250, 0.11, 10, 5000, False, 300)
+    want_fwd, want_rev = O.oracle_coverage(res, len(si.rec_prg))
+    alive = res["cl_alive"].astype(bool)
+    pairs = list(zip(res["cl_read"][alive].tolist(), res["cl_prg"][alive].tolist()))
+    assert len(pairs) > len(set(pairs))               # some (read, prg) has two surviving clusters
+    pg = api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000, coverage=True, batch_bases=4000)
+    _check_pangraph(pg, res, covg)
+    got_fwd, got_rev = pg.coverage()
+    np.testing.assert_array_equal(got_fwd, want_fwd)
+    np.testing.assert_array_equal(got_rev, want_rev)
+    assert got_fwd.max() >= 2
