@@ -4,6 +4,9 @@
 // (src/utils.cpp:338-352, src/pangenome/pangraph.cpp:43-140) and the read loop of
 // pangraph_from_read_file (src/utils.cpp:379-455).
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <condition_variable>
@@ -345,6 +348,32 @@ struct ReaderResult {
     std::string error;
 };
 
+// true iff every letter is one that nt4 (src/inthash.cpp:42-63) maps below 4: A, C, G, T in either case or
+// a raw code 0..3.  This is the reader's hot loop: 16 letters per step where SSE2 is there.
+bool all_acgt(const unsigned char *p, size_t n) {
+    size_t i = 0;
+    bool bad = false;
+#if defined(__SSE2__)
+    __m128i acc = _mm_setzero_si128();
+    const __m128i up = _mm_set1_epi8((char) 0xDF), A = _mm_set1_epi8('A'), C = _mm_set1_epi8('C'),
+                  G = _mm_set1_epi8('G'), T = _mm_set1_epi8('T'), hi = _mm_set1_epi8((char) 0xFC),
+                  zero = _mm_setzero_si128(), ones = _mm_set1_epi8((char) 0xFF);
+    for (; i + 16 <= n; i += 16) {
+        const __m128i c = _mm_loadu_si128((const __m128i *) (p + i)), u = _mm_and_si128(c, up);
+        __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, A), _mm_cmpeq_epi8(u, C)),
+                                  _mm_or_si128(_mm_cmpeq_epi8(u, G), _mm_cmpeq_epi8(u, T)));
+        ok = _mm_or_si128(ok, _mm_cmpeq_epi8(_mm_and_si128(c, hi), zero));   // c < 4
+        acc = _mm_or_si128(acc, _mm_andnot_si128(ok, ones));
+    }
+    bad = _mm_movemask_epi8(acc) != 0;
+#endif
+    for (; i < n; ++i) {
+        const unsigned char c = p[i], u = c & 0xDFu;
+        bad |= !((u == 'A') | (u == 'C') | (u == 'G') | (u == 'T') | (c < 4));
+    }
+    return !bad;
+}
+
 // The read loop of pangraph_from_read_file (src/utils.cpp:397-440) up to the point where a read is
 // handed to the sketch: ids, coverage stop, 10M-read stop, Illumina expected k-mer count.
 void reader_thread(FastaqReader *fh, const pmap_map_args_t *a, pmap_params_t prm, uint64_t batch_bases,
@@ -365,12 +394,8 @@ void reader_thread(FastaqReader *fh, const pmap_map_args_t *a, pmap_params_t prm
         fh->get_next();
         const std::string &seq = fh->read;
         // Seq::initialize -> the sketch is non-empty iff the read has a full window and only ACGT letters
-        bool sketched = seq.size() + 1 >= (uint64_t) a->w + a->k;
-        if (sketched)
-            for (unsigned char ch : seq) {
-                unsigned u = ch & 0xDFu;
-                if (!(ch < 4 || u == 'A' || u == 'C' || u == 'G' || u == 'T')) { sketched = false; break; }
-            }
+        const bool sketched = seq.size() + 1 >= (uint64_t) a->w + a->k &&
+                              all_acgt((const unsigned char *) seq.data(), seq.size());
         if (sketched) {
             covg += seq.size();                                         // :404
             if (covg / a->genome_size > a->max_covg) break;             // :405-408
