@@ -78,6 +78,18 @@ int pmap_index_upload_now(pmap_index_t *idx);
 int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg, const uint32_t *min_path_length,
                     pmap_index_t **out);
 
+/* Binary cache of a built index (no counterpart in the reference, whose
+ * Index::load re-parses the text every run).  pmap_index_save_cache writes the
+ * flat structures; source_path (may be NULL) is the `.idx` file they came
+ * from, remembered by size and modification time.  pmap_index_load_cache reads
+ * a cache back.  pmap_index_load_cached = pmap_index_load, through the cache at
+ * cache_path when it was built from this very idx_path, k and min_path_length
+ * (*from_cache = 1), else from the text, after which the cache is (re)written. */
+int pmap_index_save_cache(const pmap_index_t *idx, const char *cache_path, const char *source_path);
+int pmap_index_load_cache(const char *cache_path, pmap_index_t **out);
+int pmap_index_load_cached(const char *idx_path, uint32_t k, uint32_t n_prg, const uint32_t *min_path_length,
+                           const char *cache_path, pmap_index_t **out, int *from_cache);
+
 /* Replaces KmerGraph::load + KmerGraph::min_path_length
  * (src/kmergraph.cpp:716-820, 664-684) for one kmer-graph GFA file. */
 int pmap_gfa_min_path_length(const char *gfa_path, uint32_t *out);
@@ -106,10 +118,10 @@ void pmap_index_destroy(pmap_index_t *idx);
  * non-ACGT letter" flag per read (src/seq.cpp:49-53). */
 int pmap_reads_create(const char *bases, const uint64_t *offsets, uint32_t n_reads, uint32_t first_read_id,
                       pmap_reads_t **out);
-/* Re-runs only the device encode kernel of an uploaded batch (for measurement). */
 /* Replaces the batch held by `reads` with another one, reusing its device buffers. */
 int pmap_reads_update(pmap_reads_t *reads, const char *bases, const uint64_t *offsets, uint32_t n_reads,
                       uint32_t first_read_id);
+/* Re-runs only the device encode kernel of an uploaded batch (for measurement). */
 int pmap_reads_repack(pmap_reads_t *reads);
 int pmap_reads_info(const pmap_reads_t *reads, uint32_t *n_reads, uint64_t *n_bases, uint64_t *device_bytes);
 void pmap_reads_destroy(pmap_reads_t *reads);

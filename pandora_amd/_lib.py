@@ -70,6 +70,10 @@ SIGNATURES = {
     "pmap_reads_info": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
     "pmap_reads_destroy": (None, [C.c_void_p]),
     "pmap_fraction": (C.c_float, [C.c_float, C.c_uint32]),
+    "pmap_index_save_cache": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "pmap_index_load_cache": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "pmap_index_load_cached": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, u32p, C.c_char_p, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_int)]),
     "pmap_map": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "pmap_map_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "pmap_map_wait": (C.c_int, [C.c_void_p]),

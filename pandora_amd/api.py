@@ -73,6 +73,27 @@ class Index:
         _check(lib.pmap_index_load(str(idx_path).encode(), k, len(mpl), _p(mpl, u32p), C.byref(h)))
         return Index(h)
 
+    @staticmethod
+    def load_cached(idx_path, k, min_path_length, cache_path):
+        """Index.load through a binary cache next to the text file; returns (index, came_from_cache)."""
+        lib = _lib.load()
+        mpl = np.ascontiguousarray(min_path_length, np.uint32)
+        h = C.c_void_p()
+        hit = C.c_int(0)
+        _check(lib.pmap_index_load_cached(str(idx_path).encode(), k, len(mpl), _p(mpl, u32p), str(cache_path).encode(),
+                                          C.byref(h), C.byref(hit)))
+        return Index(h), bool(hit.value)
+
+    @staticmethod
+    def load_cache(cache_path):
+        h = C.c_void_p()
+        _check(_lib.load().pmap_index_load_cache(str(cache_path).encode(), C.byref(h)))
+        return Index(h)
+
+    def save_cache(self, cache_path, source_path=None):
+        _check(_lib.load().pmap_index_save_cache(self._h, str(cache_path).encode(),
+                                                 str(source_path).encode() if source_path else None))
+
     def upload(self):
         _check(_lib.load().pmap_index_upload_now(self._h))
 

@@ -12,9 +12,25 @@
 #include <numeric>
 #include <sstream>
 
+#include <sys/stat.h>
+
+#include <chrono>
+
 #include "pmap_internal.h"
 
 static thread_local std::string g_error;
+
+// PMAP_TRACE_INDEX=1 prints the time of every stage of an index load / build to stderr
+struct StageClock {
+    bool on = getenv("PMAP_TRACE_INDEX") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pmap index] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
 
 void pmap_set_error(const std::string &msg) { g_error = msg; }
 
@@ -47,6 +63,7 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         return pmap_fail(PMAP_EINVAL, "rec_off[n_keys] != n_recs");
     const uint64_t n_iv = d->n_recs ? d->path_off[d->n_recs] : 0;
     const uint64_t key_limit = 1ULL << (2 * d->k);
+    StageClock clk;
 
     idx->k = d->k;
     idx->n_prg = d->n_prg;
@@ -77,28 +94,44 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
             return pmap_fail(PMAP_EINVAL, "a record's path length differs from k");
     }
 
+    clk.lap("copy + validate");
     // rank of every (prg, path): order of (prg_id, prg::Path::operator<)
-    std::vector<uint32_t> by_path(d->n_recs);
-    std::iota(by_path.begin(), by_path.end(), 0u);
     auto pcmp = [&](uint32_t a, uint32_t b) {
         if (d->rec_prg[a] != d->rec_prg[b]) return d->rec_prg[a] < d->rec_prg[b] ? -1 : 1;
         uint64_t a0 = d->path_off[a], a1 = d->path_off[a + 1], b0 = d->path_off[b], b1 = d->path_off[b + 1];
         return path_cmp(d->iv_start + a0, d->iv_len + a0, a1 - a0, d->iv_start + b0, d->iv_len + b0, b1 - b0);
     };
-    std::sort(by_path.begin(), by_path.end(), [&](uint32_t a, uint32_t b) { return pcmp(a, b) < 0; });
+    // sorted on a 64-bit prefix (prg, start of the first interval) that sits next to the record number;
+    // the full comparison only breaks ties
+    struct PathKey {
+        uint64_t prefix;
+        uint32_t rec;
+    };
+    std::vector<PathKey> by_path(d->n_recs);
+    for (uint64_t j = 0; j < d->n_recs; ++j) {
+        const uint64_t first = d->path_off[j] < d->path_off[j + 1] ? d->iv_start[d->path_off[j]] : 0;
+        by_path[j] = PathKey{(uint64_t) d->rec_prg[j] << 32 | first, (uint32_t) j};
+    }
+    std::sort(by_path.begin(), by_path.end(), [&](const PathKey &a, const PathKey &b) {
+        if (a.prefix != b.prefix) return a.prefix < b.prefix;
+        return pcmp(a.rec, b.rec) < 0;
+    });
     uint32_t rank = 0;
     for (uint64_t i = 0; i < d->n_recs; ++i) {
-        if (i > 0 && pcmp(by_path[i - 1], by_path[i]) != 0) ++rank;
-        idx->path_rank[by_path[i]] = rank;
+        if (i > 0 && pcmp(by_path[i - 1].rec, by_path[i].rec) != 0) ++rank;
+        idx->path_rank[by_path[i].rec] = rank;
     }
     idx->n_paths = d->n_recs ? rank + 1 : 0;
 
+    clk.lap("path ranks");
     // group equal keys (Index::load appends the records of a repeated key line, src/index.cpp:97-110)
+    std::vector<std::pair<uint64_t, uint64_t>> kpairs(d->n_keys);   // (key, position in the caller's list)
+    for (uint64_t i = 0; i < d->n_keys; ++i) kpairs[i] = {d->keys[i], i};
+    std::sort(kpairs.begin(), kpairs.end());
     std::vector<uint64_t> korder(d->n_keys);
-    std::iota(korder.begin(), korder.end(), 0ull);
-    std::sort(korder.begin(), korder.end(), [&](uint64_t a, uint64_t b) {
-        return d->keys[a] != d->keys[b] ? d->keys[a] < d->keys[b] : a < b;
-    });
+    for (uint64_t i = 0; i < d->n_keys; ++i) korder[i] = kpairs[i].second;
+    kpairs.clear();
+    kpairs.shrink_to_fit();
     idx->recs.clear();
     idx->recs.reserve(d->n_recs);
     std::vector<uint64_t> ukeys;
@@ -143,6 +176,7 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         }
     }
     idx->n_keys = ukeys.size();
+    clk.lap("group keys, order records");
 
     uint32_t log2cap = 6;
     while ((1ull << log2cap) < 2 * idx->n_keys) ++log2cap;
@@ -169,32 +203,40 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
             idx->filter[b >> 5] |= 1u << (b & 31);
         }
     }
+    clk.lap("table + filter");
     return PMAP_OK;
 }
 
 // ---------------------------------------------------------------------------
 // text formats
 
+static inline bool is_digit(char c) { return (unsigned) (c - '0') < 10u; }
+
 struct Cursor {
     const char *p, *end;
     bool more() const { return p < end; }
     bool read_uint(uint64_t *v) {   // skips anything that is not a digit first
-        while (p < end && !isdigit((unsigned char) *p)) ++p;
+        while (p < end && !is_digit(*p)) ++p;
         if (p >= end) return false;
         uint64_t x = 0;
-        while (p < end && isdigit((unsigned char) *p)) x = x * 10 + (uint64_t) (*p++ - '0');
+        while (p < end && is_digit(*p)) x = x * 10 + (uint64_t) (*p++ - '0');
         *v = x;
         return true;
     }
 };
 
 static bool slurp(const char *path, std::string *out) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f.is_open()) return false;
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    *out = ss.str();
-    return true;
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    bool ok = fseek(f, 0, SEEK_END) == 0;
+    const long size = ok ? ftell(f) : -1;
+    ok = ok && size >= 0 && fseek(f, 0, SEEK_SET) == 0;
+    if (ok) {
+        out->resize((size_t) size);
+        ok = size == 0 || fread(&(*out)[0], 1, (size_t) size, f) == (size_t) size;
+    }
+    fclose(f);
+    return ok;
 }
 
 // MiniRecord text `(prg, N{[s, e)[s, e)...}, knode, strand)` (src/minirecord.cpp:23-38,
@@ -223,9 +265,12 @@ static bool parse_record(Cursor &c, uint32_t *prg, std::vector<uint32_t> *ivs, s
 extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg, const uint32_t *mpl,
                                pmap_index_t **out) {
     std::string text;
+    StageClock clk0;
     if (!slurp(idx_path, &text))
         return pmap_fail(PMAP_EIO, std::string("Unable to open index file ") + idx_path +
                                        ". Does it exist? Have you run pandora index?");   // src/index.cpp:115
+    clk0.lap("read file");
+    StageClock clk;
     Cursor c{text.data(), text.data() + text.size()};
     std::vector<uint64_t> keys, rec_off{0}, path_off{0};
     std::vector<uint32_t> rec_prg, rec_knode, ivs, ivl;
@@ -235,7 +280,7 @@ extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg,
     // or a key followed by its record count; anything else starts a record
     while (c.more()) {
         char ch = *c.p;
-        if (isdigit((unsigned char) ch)) {
+        if (is_digit(ch)) {
             uint64_t v;
             c.read_uint(&v);
             if (first) { first = false; continue; }
@@ -258,6 +303,7 @@ extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg,
         }
     }
     if (!keys.empty()) rec_off.push_back(rec_prg.size());
+    clk.lap("parse text");
     uint32_t need_prg = 0;
     for (uint32_t p : rec_prg) need_prg = std::max(need_prg, p + 1);
     std::vector<uint32_t> mplv(std::max(n_prg, need_prg), 0);
@@ -278,6 +324,214 @@ extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg,
     d.n_prg = (uint32_t) mplv.size();
     d.min_path_length = mplv.data();
     return pmap_index_create(&d, out);
+}
+
+// ---------------------------------------------------------------------------
+// Binary cache of a built index: the text format costs seconds per million records to parse and
+// rank; the cache is read back at file speed.  Layout: CacheHeader, then the arrays in the order of
+// cache_arrays(), each padded to 64 bytes, then the magic once more.
+
+namespace {
+
+struct CacheHeader {
+    char magic[8];               // "PMAPIDX1"
+    uint32_t version, k, n_prg, log2cap, filter_bits, pad;
+    uint64_t n_keys, n_recs, n_paths, n_iv, n_slots, n_filter_words;
+    uint64_t src_size, src_mtime_ns, mpl_hash;   // what the cache was built from
+};
+const char CACHE_MAGIC[8] = {'P', 'M', 'A', 'P', 'I', 'D', 'X', '1'};
+const uint32_t CACHE_VERSION = 1;
+
+uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *p = (const unsigned char *) data;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+struct ArrayRef {
+    void *data;
+    size_t bytes;
+};
+
+// every array of the index, sized from the header (resizes the vectors when `size_them` is set)
+std::vector<ArrayRef> cache_arrays(pmap_index *idx, const CacheHeader &h, bool size_them) {
+    if (size_them) {
+        idx->key_of_rec.resize(h.n_recs);
+        idx->rec_prg.resize(h.n_recs);
+        idx->rec_knode.resize(h.n_recs);
+        idx->path_rank.resize(h.n_recs);
+        idx->rec_strand.resize(h.n_recs);
+        idx->path_off.resize(h.n_recs + 1);
+        idx->iv_start.resize(h.n_iv);
+        idx->iv_len.resize(h.n_iv);
+        idx->min_path_length.resize(h.n_prg);
+        idx->slots.resize(h.n_slots);
+        idx->recs.resize(h.n_recs);
+        idx->filter.resize(h.n_filter_words);
+    }
+    return {{idx->key_of_rec.data(), h.n_recs * sizeof(uint64_t)},
+            {idx->rec_prg.data(), h.n_recs * sizeof(uint32_t)},
+            {idx->rec_knode.data(), h.n_recs * sizeof(uint32_t)},
+            {idx->path_rank.data(), h.n_recs * sizeof(uint32_t)},
+            {idx->rec_strand.data(), h.n_recs},
+            {idx->path_off.data(), (h.n_recs + 1) * sizeof(uint64_t)},
+            {idx->iv_start.data(), h.n_iv * sizeof(uint32_t)},
+            {idx->iv_len.data(), h.n_iv * sizeof(uint32_t)},
+            {idx->min_path_length.data(), h.n_prg * sizeof(uint32_t)},
+            {idx->slots.data(), h.n_slots * sizeof(PmapSlot)},
+            {idx->recs.data(), h.n_recs * sizeof(PmapRec)},
+            {idx->filter.data(), h.n_filter_words * sizeof(uint32_t)}};
+}
+
+bool source_stamp(const char *path, uint64_t *size, uint64_t *mtime_ns) {
+    struct stat st;
+    if (!path || stat(path, &st) != 0) return false;
+    *size = (uint64_t) st.st_size;
+    *mtime_ns = (uint64_t) st.st_mtim.tv_sec * 1000000000ull + (uint64_t) st.st_mtim.tv_nsec;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int pmap_index_save_cache(const pmap_index_t *cidx, const char *cache_path, const char *source_path) {
+    if (!cidx || !cache_path) return pmap_fail(PMAP_EINVAL, "null argument");
+    pmap_index *idx = const_cast<pmap_index *>(cidx);
+    CacheHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, CACHE_MAGIC, 8);
+    h.version = CACHE_VERSION;
+    h.k = idx->k;
+    h.n_prg = idx->n_prg;
+    h.log2cap = idx->log2cap;
+    h.filter_bits = idx->filter_bits;
+    h.n_keys = idx->n_keys;
+    h.n_recs = idx->n_recs;
+    h.n_paths = idx->n_paths;
+    h.n_iv = idx->iv_start.size();
+    h.n_slots = idx->slots.size();
+    h.n_filter_words = idx->filter.size();
+    if (source_path && !source_stamp(source_path, &h.src_size, &h.src_mtime_ns))
+        return pmap_fail(PMAP_EIO, std::string("cannot stat ") + source_path);
+    h.mpl_hash = fnv1a(idx->min_path_length.data(), idx->min_path_length.size() * sizeof(uint32_t));
+    // written under a temporary name and renamed: a reader never sees half a cache
+    const std::string tmp = std::string(cache_path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return pmap_fail(PMAP_EIO, std::string("cannot write ") + tmp);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    static const char zeros[64] = {0};
+    for (const ArrayRef &a : cache_arrays(idx, h, false)) {
+        if (ok && a.bytes) ok = fwrite(a.data, 1, a.bytes, f) == a.bytes;
+        const size_t padn = (64 - a.bytes % 64) % 64;
+        if (ok && padn) ok = fwrite(zeros, 1, padn, f) == padn;
+    }
+    ok = ok && fwrite(CACHE_MAGIC, 8, 1, f) == 1;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), cache_path) != 0) {
+        remove(tmp.c_str());
+        return pmap_fail(PMAP_EIO, std::string("cannot write ") + cache_path);
+    }
+    return PMAP_OK;
+}
+
+extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out) {
+    if (!cache_path || !out) return pmap_fail(PMAP_EINVAL, "null argument");
+    StageClock clk;
+    FILE *f = fopen(cache_path, "rb");
+    if (!f) return pmap_fail(PMAP_EIO, std::string("Unable to open index cache ") + cache_path);
+    CacheHeader h;
+    auto bad = [&](const char *why) {
+        fclose(f);
+        return pmap_fail(PMAP_EIO, std::string("index cache ") + cache_path + ": " + why);
+    };
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, CACHE_MAGIC, 8) != 0) return bad("not an index cache");
+    if (h.version != CACHE_VERSION) return bad("written by another version");
+    if (h.k < 1 || h.k > 31 || h.log2cap > 31 || h.n_slots != (1ull << h.log2cap) || h.n_recs >= 0xFFFFFFFFull ||
+        h.n_keys > h.n_recs || h.filter_bits > 24 ||
+        h.n_filter_words != (h.filter_bits ? (1ull << (h.filter_bits - 5)) : 0))
+        return bad("inconsistent header");
+    // the file must be exactly as long as the header says, before anything is allocated from it
+    uint64_t expect = sizeof(h) + 8;
+    const uint64_t sizes[] = {h.n_recs * 8, h.n_recs * 4, h.n_recs * 4, h.n_recs * 4, h.n_recs, (h.n_recs + 1) * 8,
+                              h.n_iv * 4, h.n_iv * 4, (uint64_t) h.n_prg * 4, h.n_slots * 16, h.n_recs * 16,
+                              h.n_filter_words * 4};
+    for (uint64_t b : sizes) expect += (b + 63) / 64 * 64;
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0 || (uint64_t) st.st_size != expect) return bad("truncated or damaged");
+    pmap_index *idx = new pmap_index();
+    idx->k = h.k;
+    idx->n_prg = h.n_prg;
+    idx->log2cap = h.log2cap;
+    idx->filter_bits = h.filter_bits;
+    idx->n_keys = h.n_keys;
+    idx->n_recs = h.n_recs;
+    idx->n_paths = h.n_paths;
+    bool ok = true;
+    char skip[64];
+    for (const ArrayRef &a : cache_arrays(idx, h, true)) {
+        if (ok && a.bytes) ok = fread(a.data, 1, a.bytes, f) == a.bytes;
+        const size_t padn = (64 - a.bytes % 64) % 64;
+        if (ok && padn) ok = fread(skip, 1, padn, f) == padn;
+    }
+    char tail[8];
+    ok = ok && fread(tail, 8, 1, f) == 1 && memcmp(tail, CACHE_MAGIC, 8) == 0;
+    // cheap structural checks: everything the kernels index with stays in range
+    if (ok) {
+        ok = idx->path_off[h.n_recs] == h.n_iv;
+        uint64_t used = 0;
+        for (const PmapSlot &sl : idx->slots)
+            if (sl.key != PMAP_EMPTY_KEY) {
+                ++used;
+                if ((uint64_t) sl.off + sl.cnt > h.n_recs || sl.cnt == 0) ok = false;
+            }
+        if (used != h.n_keys) ok = false;
+        for (const PmapRec &r : idx->recs)
+            if (r.prg >= h.n_prg || r.orig >= h.n_recs) ok = false;
+    }
+    if (!ok) {
+        delete idx;
+        return bad("truncated or damaged");
+    }
+    fclose(f);
+    clk.lap("load cache");
+    *out = idx;
+    return PMAP_OK;
+}
+
+extern "C" int pmap_index_load_cached(const char *idx_path, uint32_t k, uint32_t n_prg, const uint32_t *mpl,
+                                      const char *cache_path, pmap_index_t **out, int *from_cache) {
+    if (!idx_path || !cache_path || !out) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (from_cache) *from_cache = 0;
+    uint64_t size = 0, mtime = 0;
+    if (!source_stamp(idx_path, &size, &mtime))
+        return pmap_fail(PMAP_EIO, std::string("Unable to open index file ") + idx_path +
+                                       ". Does it exist? Have you run pandora index?");   // src/index.cpp:115
+    FILE *f = fopen(cache_path, "rb");
+    if (f) {
+        CacheHeader h;
+        const bool have = fread(&h, sizeof(h), 1, f) == 1;
+        fclose(f);
+        // usable only if built from this very file with these parameters
+        if (have && memcmp(h.magic, CACHE_MAGIC, 8) == 0 && h.version == CACHE_VERSION && h.k == k &&
+            h.src_size == size && h.src_mtime_ns == mtime) {
+            pmap_index_t *idx = nullptr;
+            if (pmap_index_load_cache(cache_path, &idx) == PMAP_OK) {
+                // min_path_length shorter than the cache's table was padded with zeros when it was built
+                std::vector<uint32_t> mplv(idx->n_prg, 0);
+                if (mpl) std::copy(mpl, mpl + std::min<uint32_t>(n_prg, idx->n_prg), mplv.begin());
+                if (n_prg <= idx->n_prg && fnv1a(mplv.data(), mplv.size() * sizeof(uint32_t)) == h.mpl_hash) {
+                    if (from_cache) *from_cache = 1;
+                    *out = idx;
+                    return PMAP_OK;
+                }
+                pmap_index_destroy(idx);
+            }
+        }
+    }
+    int rc = pmap_index_load(idx_path, k, n_prg, mpl, out);
+    if (rc) return rc;
+    // a cache that cannot be written is not an error of the load
+    if (pmap_index_save_cache(*out, cache_path, idx_path) != PMAP_OK) pmap_set_error("");
+    return PMAP_OK;
 }
 
 extern "C" int pmap_index_create(const pmap_index_desc_t *desc, pmap_index_t **out) {

@@ -152,6 +152,69 @@ def test_index_text_round_trip(tmp_path):
     np.testing.assert_array_equal(rec["iv_len"], si.iv_len)
 
 
+def _write_idx_text(si, path):
+    lines = [str(len(si.keys))]
+    for i, key in enumerate(si.keys):
+        recs = []
+        for j in range(int(si.rec_off[i]), int(si.rec_off[i + 1])):
+            a, b = int(si.path_off[j]), int(si.path_off[j + 1])
+            ivs = "".join("[%d, %d)" % (si.iv_start[q], si.iv_start[q] + si.iv_len[q]) for q in range(a, b))
+            recs.append("(%d, %d{%s}, %d, %d)" % (si.rec_prg[j], b - a, ivs, si.rec_knode[j], si.rec_strand[j]))
+        lines.append("%d\t%d\t%s" % (key, len(recs), "\t".join(recs)))
+    path.write_text("\n".join(lines) + "\n")
+
+
+def _same_index(a, b):
+    ia, ib = a.info(), b.info()
+    for f in ("k", "n_keys", "n_recs", "n_paths", "table_slots", "n_prg"):
+        assert ia[f] == ib[f], f
+    ra, rb = a.records(), b.records()
+    for f in ra:
+        np.testing.assert_array_equal(ra[f], rb[f], err_msg=f)
+
+
+def test_index_binary_cache(tmp_path):
+    rng = np.random.default_rng(4)
+    si = synth.build_index([synth.random_dna(400, rng) for _ in range(8)], 5, 11, rng=rng, split_paths=0.3)
+    txt, cache = tmp_path / "p.idx", tmp_path / "p.idx.pmapcache"
+    _write_idx_text(si, txt)
+    ref = api.Index.load(txt, 11, si.min_path_length)
+    a, hit = api.Index.load_cached(txt, 11, si.min_path_length, cache)
+    assert not hit and cache.exists()
+    _same_index(ref, a)
+    b, hit = api.Index.load_cached(txt, 11, si.min_path_length, cache)
+    assert hit
+    _same_index(ref, b)
+    _same_index(ref, api.Index.load_cache(cache))
+    # other parameters or a changed text file: the cache is not used, and is rewritten
+    mpl2 = np.array(si.min_path_length, np.uint32)
+    mpl2[0] += 1
+    c, hit = api.Index.load_cached(txt, 11, mpl2, cache)
+    assert not hit
+    c, hit = api.Index.load_cached(txt, 11, mpl2, cache)
+    assert hit
+    os.utime(txt, ns=(1, 1))
+    c, hit = api.Index.load_cached(txt, 11, mpl2, cache)
+    assert not hit
+    # explicit save / load, damaged files
+    other = tmp_path / "other.cache"
+    ref.save_cache(other)
+    _same_index(ref, api.Index.load_cache(other))
+    raw = other.read_bytes()
+    for bad in (raw[:len(raw) // 2], b"PMAPIDX0" + raw[8:], raw[:-8] + b"XXXXXXXX", raw + b"\0" * 64, b""):
+        (tmp_path / "bad.cache").write_bytes(bad)
+        with pytest.raises(api.PmapError) as e:
+            api.Index.load_cache(tmp_path / "bad.cache")
+        assert e.value.code == 3
+    with pytest.raises(api.PmapError):
+        api.Index.load_cache(tmp_path / "missing.cache")
+    # a damaged cache next to a good text file: falls back to the text
+    cache.write_bytes(raw[:100])
+    d, hit = api.Index.load_cached(txt, 11, mpl2, cache)
+    assert not hit
+    assert api.Index.load_cached(txt, 11, mpl2, cache)[1]
+
+
 def test_gfa_min_path_length(tmp_path):
     cases = list(RC.BIGGER_INFER["graphs"].values()) + list(RC.SIMPLE_INFER["graphs"].values())
     for i, (paths, edges) in enumerate(cases):
