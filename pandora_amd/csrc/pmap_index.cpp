@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <thread>
 
 #include "pmap_internal.h"
 
@@ -31,6 +32,39 @@ struct StageClock {
         t = now;
     }
 };
+
+static unsigned worker_count(size_t items, size_t min_per_worker) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    hw = std::min(hw, 16u);
+    return (unsigned) std::max<size_t>(1, std::min<size_t>(hw, items / std::max<size_t>(min_per_worker, 1)));
+}
+
+// std::sort over worker threads: sorted runs, then pairwise merges
+template <typename T, typename Less>
+static void parallel_sort(std::vector<T> &v, Less less) {
+    const unsigned nw = worker_count(v.size(), 1u << 16);
+    if (nw <= 1) {
+        std::sort(v.begin(), v.end(), less);
+        return;
+    }
+    std::vector<size_t> cut(nw + 1);
+    for (unsigned i = 0; i <= nw; ++i) cut[i] = v.size() * i / nw;
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nw; ++i)
+            th.emplace_back([&, i] { std::sort(v.begin() + cut[i], v.begin() + cut[i + 1], less); });
+        for (auto &t : th) t.join();
+    }
+    for (unsigned width = 1; width < nw; width *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i + width < nw; i += 2 * width) {
+            const size_t a = cut[i], m = cut[i + width], b = cut[std::min(i + 2 * width, nw)];
+            th.emplace_back([&, a, m, b] { std::inplace_merge(v.begin() + a, v.begin() + m, v.begin() + b, less); });
+        }
+        for (auto &t : th) t.join();
+    }
+}
 
 void pmap_set_error(const std::string &msg) { g_error = msg; }
 
@@ -112,7 +146,7 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         const uint64_t first = d->path_off[j] < d->path_off[j + 1] ? d->iv_start[d->path_off[j]] : 0;
         by_path[j] = PathKey{(uint64_t) d->rec_prg[j] << 32 | first, (uint32_t) j};
     }
-    std::sort(by_path.begin(), by_path.end(), [&](const PathKey &a, const PathKey &b) {
+    parallel_sort(by_path, [&](const PathKey &a, const PathKey &b) {
         if (a.prefix != b.prefix) return a.prefix < b.prefix;
         return pcmp(a.rec, b.rec) < 0;
     });
@@ -127,7 +161,9 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
     // group equal keys (Index::load appends the records of a repeated key line, src/index.cpp:97-110)
     std::vector<std::pair<uint64_t, uint64_t>> kpairs(d->n_keys);   // (key, position in the caller's list)
     for (uint64_t i = 0; i < d->n_keys; ++i) kpairs[i] = {d->keys[i], i};
-    std::sort(kpairs.begin(), kpairs.end());
+    parallel_sort(kpairs, [](const std::pair<uint64_t, uint64_t> &a, const std::pair<uint64_t, uint64_t> &b) {
+        return a < b;
+    });
     std::vector<uint64_t> korder(d->n_keys);
     for (uint64_t i = 0; i < d->n_keys; ++i) korder[i] = kpairs[i].second;
     kpairs.clear();
@@ -271,38 +307,92 @@ extern "C" int pmap_index_load(const char *idx_path, uint32_t k, uint32_t n_prg,
                                        ". Does it exist? Have you run pandora index?");   // src/index.cpp:115
     clk0.lap("read file");
     StageClock clk;
-    Cursor c{text.data(), text.data() + text.size()};
+    // One line of the file is one key with its records (Index::save, src/index.cpp:51-68), so pieces cut
+    // at line starts ("\n" + digit, after a record's closing bracket or the count line) parse independently.
+    struct Piece {
+        const char *begin, *end;
+        std::vector<uint64_t> keys, rec_off, path_off;    // offsets relative to the piece
+        std::vector<uint32_t> rec_prg, rec_knode, ivs, ivl;
+        std::vector<uint8_t> rec_strand;
+        const char *error = nullptr;
+    };
+    const char *t0 = text.data(), *t1 = text.data() + text.size();
+    // Index::load (src/index.cpp:86-113): the first token that starts with a digit is the entry count
+    const char *body = t0;
+    while (body < t1 && !is_digit(*body)) {
+        if (*body == '(') return pmap_fail(PMAP_EIO, "index file: record before any key");
+        ++body;
+    }
+    while (body < t1 && is_digit(*body)) ++body;
+    const unsigned n_pieces = worker_count((size_t) (t1 - body), 4u << 20);
+    std::vector<Piece> pieces(n_pieces);
+    {
+        const char *cur = body;
+        for (unsigned i = 0; i < n_pieces; ++i) {
+            const char *stop = t1;
+            if (i + 1 < n_pieces) {
+                stop = body + (size_t) (t1 - body) * (i + 1) / n_pieces;
+                if (stop < cur) stop = cur;
+                while (stop < t1 && !(stop > t0 + 1 && stop[-1] == '\n' && is_digit(*stop) &&
+                                      (stop[-2] == ')' || stop[-2] == '\t' || is_digit(stop[-2]))))
+                    ++stop;
+            }
+            pieces[i].begin = cur;
+            pieces[i].end = stop;
+            cur = stop;
+        }
+    }
+    auto parse_piece = [](Piece *pc) {
+        Cursor c{pc->begin, pc->end};
+        // a token starting with a digit is a key followed by its record count; '(' starts a record
+        while (c.more()) {
+            char ch = *c.p;
+            if (is_digit(ch)) {
+                uint64_t v, cnt;
+                c.read_uint(&v);
+                if (!c.read_uint(&cnt)) { pc->error = "index file: key without record count"; return; }
+                if (!pc->keys.empty()) pc->rec_off.push_back(pc->rec_prg.size());
+                pc->keys.push_back(v);
+            } else if (ch == '(') {
+                if (pc->keys.empty()) { pc->error = "index file: record before any key"; return; }
+                uint32_t prg, knode;
+                uint8_t strand;
+                if (!parse_record(c, &prg, &pc->ivs, &pc->ivl, &knode, &strand)) {
+                    pc->error = "index file: malformed record";
+                    return;
+                }
+                pc->rec_prg.push_back(prg);
+                pc->rec_knode.push_back(knode);
+                pc->rec_strand.push_back(strand);
+                pc->path_off.push_back(pc->ivs.size());
+            } else {
+                ++c.p;
+            }
+        }
+        if (!pc->keys.empty()) pc->rec_off.push_back(pc->rec_prg.size());
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < n_pieces; ++i) th.emplace_back(parse_piece, &pieces[i]);
+        parse_piece(&pieces[0]);
+        for (auto &t : th) t.join();
+    }
     std::vector<uint64_t> keys, rec_off{0}, path_off{0};
     std::vector<uint32_t> rec_prg, rec_knode, ivs, ivl;
     std::vector<uint8_t> rec_strand;
-    bool first = true;
-    // Index::load (src/index.cpp:86-113): a token starting with a digit is the entry count (first)
-    // or a key followed by its record count; anything else starts a record
-    while (c.more()) {
-        char ch = *c.p;
-        if (is_digit(ch)) {
-            uint64_t v;
-            c.read_uint(&v);
-            if (first) { first = false; continue; }
-            uint64_t cnt;
-            if (!c.read_uint(&cnt)) return pmap_fail(PMAP_EIO, "index file: key without record count");
-            if (!keys.empty()) rec_off.push_back(rec_prg.size());
-            keys.push_back(v);
-        } else if (ch == '(') {
-            if (keys.empty()) return pmap_fail(PMAP_EIO, "index file: record before any key");
-            uint32_t prg, knode;
-            uint8_t strand;
-            if (!parse_record(c, &prg, &ivs, &ivl, &knode, &strand))
-                return pmap_fail(PMAP_EIO, "index file: malformed record");
-            rec_prg.push_back(prg);
-            rec_knode.push_back(knode);
-            rec_strand.push_back(strand);
-            path_off.push_back(ivs.size());
-        } else {
-            ++c.p;
-        }
+    for (Piece &pc : pieces) {
+        if (pc.error) return pmap_fail(PMAP_EIO, pc.error);
+        const uint64_t r0 = rec_prg.size(), i0 = ivs.size();
+        keys.insert(keys.end(), pc.keys.begin(), pc.keys.end());
+        for (uint64_t o : pc.rec_off) rec_off.push_back(r0 + o);
+        for (uint64_t o : pc.path_off) path_off.push_back(i0 + o);
+        rec_prg.insert(rec_prg.end(), pc.rec_prg.begin(), pc.rec_prg.end());
+        rec_knode.insert(rec_knode.end(), pc.rec_knode.begin(), pc.rec_knode.end());
+        rec_strand.insert(rec_strand.end(), pc.rec_strand.begin(), pc.rec_strand.end());
+        ivs.insert(ivs.end(), pc.ivs.begin(), pc.ivs.end());
+        ivl.insert(ivl.end(), pc.ivl.begin(), pc.ivl.end());
+        pc = Piece();
     }
-    if (!keys.empty()) rec_off.push_back(rec_prg.size());
     clk.lap("parse text");
     uint32_t need_prg = 0;
     for (uint32_t p : rec_prg) need_prg = std::max(need_prg, p + 1);
