@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
     if (lane == 0) ((uint32_t *) (tile_cnt + g))[2] = mine;
 }
 
-// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A block of 16 wavefronts takes 256
-// tiles, a wavefront 16 of them (the work of a wavefront is a chain of dependent loads: many short
-// chains hide the latency better than few long ones).  The block's first hit is the chained prefix sum of the blocks'
+// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A block of 16 wavefronts takes 1024
+// tiles, a wavefront 64 of them (few, big blocks: the chained prefix sum costs more the more
+// blocks poll each other).  The block's first hit is the chained prefix sum of the blocks'
 // hit counts; batch totals are added to the counters.  A wavefront numbers its entries
 // consecutively (tile by tile, so still in (read, position) order); lane e takes entry e, finds
 // its tile by a search over the per-tile prefix sums held in the lanes, and writes the entry's

@@ -298,9 +298,9 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     uint4 *__restrict__ tile_cnt, unsigned long long *__restrict__ state, uint32_t n_state_words,
     uint32_t *__restrict__ hbounds, uint32_t n_hb) {
     const uint32_t w = WC ? (uint32_t) WC : w_arg;
-    {
-        // housekeeping for the kernels that follow in the stream: zero the counters and the words of
-        // the chained prefix sums, set the per-read hit bounds to all-ones
+    // housekeeping for the kernels that follow in the stream, by the first blocks only: zero the
+    // counters and the words of the chained prefix sums, set the per-read hit bounds to all-ones
+    if (blockIdx.x * 256u < (n_state_words > n_hb ? n_state_words : n_hb)) {
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
         for (uint32_t i = gid; i < n_state_words; i += gsz) state[i] = 0ull;
         for (uint32_t i = gid; i < n_hb; i += gsz) hbounds[i] = 0xFFFFFFFFu;
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     __shared__ __align__(16) HT sH[4][WAVE_POS];
     __shared__ __align__(16) HT sL[4][WAVE_POS + 8];
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wavefront's number is the same in every lane: kept in a scalar register, so is everything
+    // derived from it (tile position, LDS slice addresses)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * 4 + wv;
     if (g >= n_tiles) return;                       // whole wavefront leaves; nothing below uses a block barrier
     uint32_t *W = sW[wv], *mstart = sStart[wv], *mlen = sLen[wv], *wr = sRead[wv];
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     const uint32_t off0 = (uint32_t) (P0 & 15);                 // 0, 4, 8 or 12
     const uint32_t P0lo = (uint32_t) P0;                        // positions are below 2^32; wrapping is harmless
     if (lane < SK_NW) {
-        const int64_t wi = wbase + lane;
+        const int32_t wi = (int32_t) wbase + lane;      // word indices are below 2^28
         uint32_t word = 0, ms = 0, ml = 0, ri = 0;
-        if (wi >= 0 && wi < (int64_t) n_words) {
+        if (wi >= 0 && wi < (int32_t) n_words) {
             const uint2 wd = words[wi];
             word = wd.x;
             ri = wd.y;
@@ -348,8 +350,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     // byte selector that funnels the 4 bytes starting (lane's misalignment) bytes into a word pair;
     // the misalignment is the same for both quads of the lane (they are 64 quads = 16 words apart)
     const uint32_t mis = ((uint32_t) lane + (off0 >> 2)) & 3u;     // quad inside its packed word
-    uint32_t bsel = mis | (mis << 8);
-    bsel = 0x07060504u - (bsel | (bsel << 16));
+    const uint32_t bsel = mis == 0 ? 0x07060504u : mis == 1 ? 0x06050403u : mis == 2 ? 0x05040302u : 0x04030201u;
     // Positions that are no k-mer of a read (padding, reads too short or with a bad letter) get
     // hashes of whatever bits are there: they never reach a result, because a window minimum counts
     // only if its whole window lies inside one read, and a flag only at a real k-mer.
