@@ -230,8 +230,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32" if prm["k"] <= 15 else "u64",
             "data": "synthetic",
-            "config": {"workload": "%s: 1000-locus synthetic PRG index, %d reads/GPU (%d bases/GPU), w=%d k=%d"
-                                   % (args.workload, cn["n_reads"], cn["n_bases"], prm["w"], prm["k"]),
+            "config": {"workload": "%s: %d-locus synthetic PRG index, %d reads/GPU (%d bases/GPU), w=%d k=%d"
+                                   % (args.workload, si.n_prg, cn["n_reads"], cn["n_bases"], prm["w"], prm["k"]),
                        "reads_per_gpu": cn["n_reads"], "bases_per_gpu": cn["n_bases"],
                        "minimizers_per_gpu": cn["n_minimizers"], "hits_per_gpu": cn["n_hits"],
                        "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
     }
     if (active) {
         const uint32_t d = s + c;
+        if (d >= n_hits) return;          // only with inconsistent segment bounds: never write out of range
         s_read[d] = r;
         s_key[d] = key;
         s_pos[d] = h_pos[i];
