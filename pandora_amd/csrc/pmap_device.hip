@@ -89,17 +89,16 @@ struct DevBuf {
 };
 
 // counters kept in device memory for the whole pipeline, read back once per call
-static const int TOTAL_LANES = 64;   // batch totals are accumulated in 64 separate words each, summed by the host
 struct Counters {
-    unsigned long long n_hits;    // hits of the batch as the chained prefix sum gives them (low 32 bits exact)
+    unsigned long long n_hits;    // hits of the batch
+    unsigned long long n_mini;    // minimizers of the batch
+    unsigned long long n_ent;     // entries handed to the scatter (all minimizers, or only those with hits)
     unsigned long long n_cl;      // clusters before the size threshold
     unsigned long long n_kept;    // clusters kept
     uint32_t fail;                // a chained prefix sum gave up waiting
-    uint32_t pad[9];
-    // [0] minimizers, [1] entries handed to the scatter (all minimizers, or only those with hits), [2] hits
-    unsigned long long totals[3][TOTAL_LANES];
+    uint32_t pad[5];
 };
-static_assert(sizeof(Counters) % 16 == 0, "Counters is the head of the state block");
+static_assert(sizeof(Counters) == 64, "Counters is the head of the state block");
 
 #include "pmap_kernels.hip.h"
 
@@ -134,7 +133,8 @@ struct pmap_result {
     uint32_t hit_cap = 0, cl_cap = 0;
     // state block, zeroed before every run: Counters, then the 8-byte words of the three chained prefix sums
     DevBuf state;
-    uint32_t n_sblk = 0, n_ablk = 0, n_bblk = 0;   // blocks of the scatter, cluster cut and cluster keep kernels
+    uint32_t n_ablk = 0, n_bblk = 0;   // blocks of the cluster cut and cluster keep kernels
+    DevBuf group_sum;                  // uint4 per group of GROUP_TILES tiles: minimizers, entries, hits
     // per tile
     DevBuf tile_cnt, bsum, scratch_total;
     // tile-slotted entries
@@ -163,7 +163,7 @@ struct pmap_result {
     uint32_t p_last = 0;
     uint32_t kt_recorded = 0;
     std::vector<DevBuf *> all() {
-        return {&state, &tile_cnt, &bsum, &scratch_total, &mkmer, &ents, &h_read, &h_key, &h_pos, &h_rank, &h_rec,
+        return {&state, &group_sum, &tile_cnt, &bsum, &scratch_total, &mkmer, &ents, &h_read, &h_key, &h_pos, &h_rank, &h_rec,
                 &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &cstart, &k_rows, &thr};
     }
 };
@@ -418,15 +418,15 @@ static int run_pipeline(pmap_result *res) {
     const bool k32 = k <= 15;
     const uint32_t n_tiles = res->n_tiles;
     // state block: counters + one 8-byte word per block of each chained prefix sum
-    res->n_sblk = (n_tiles + SCATTER_WAVES * SCATTER_TILES - 1) / (SCATTER_WAVES * SCATTER_TILES);
     res->n_ablk = res->hit_cap / CUT_BLOCK;
     res->n_bblk = res->cl_cap / KEEP_THREADS;
     const size_t state_bytes =
-        (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_sblk + res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
+        (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
     if ((rc = res->state.ensure(state_bytes))) return rc;
     Counters *dc = res->state.as<Counters>();
-    unsigned long long *gran_s = (unsigned long long *) (dc + 1), *gran_a = gran_s + res->n_sblk,
-                       *gran_b = gran_a + res->n_ablk;
+    unsigned long long *gran_a = (unsigned long long *) (dc + 1), *gran_b = gran_a + res->n_ablk;
+    const uint32_t n_groups = (uint32_t) (((size_t) n_tiles + GROUP_TILES - 1) / GROUP_TILES);
+    if ((rc = res->group_sum.ensure(sizeof(uint4) * ((size_t) n_groups + 1)))) return rc;
     if (n_tiles == 0) {           // empty batch: nothing to launch
         memset(res->hc, 0, sizeof(Counters));
         res->kt_recorded = 0;
@@ -434,7 +434,11 @@ static int run_pipeline(pmap_result *res) {
         return PMAP_OK;
     }
     // the sketch kernel clears the state block and the read bounds for the kernels after it
-    const uint32_t n_state_words = (uint32_t) (state_bytes / 8), n_hb = 2 * (rd->n_reads + 1);
+    SketchAux aux;
+    aux.state = res->state.as<unsigned long long>();
+    aux.n_state_words = (uint32_t) (state_bytes / 8);
+    aux.hbounds = res->hbounds.as<uint32_t>();
+    aux.n_hb = 2 * (rd->n_reads + 1);
     g_kt = &kt;
 
     // ---- sketch (+ probe when fused)
@@ -443,7 +447,7 @@ static int run_pipeline(pmap_result *res) {
 #define SKETCH_ARGS                                                                                                   \
     rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, idx->d_slots, idx->log2cap,            \
         idx->d_filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>(), \
-        res->state.as<unsigned long long>(), n_state_words, res->hbounds.as<uint32_t>(), n_hb
+        aux
 #define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
     KLAUNCH(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
         // w = 14 (the default of pandora map) and w = 1 (dense sketches) have their own instantiations
@@ -474,8 +478,12 @@ static int run_pipeline(pmap_result *res) {
             kt.end(KT_PROBE);
         }
         kt.begin(KT_SCATTER);
-        KLAUNCH_B(scatter_group_kernel, dim3(res->n_sblk), 64 * SCATTER_WAVES, res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
-                idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, gran_s, rd->n_reads + 1, res->hbounds.as<uint32_t>(),
+        const uint32_t n_waves = (n_tiles + SCATTER_TILES - 1) / SCATTER_TILES;
+        KLAUNCH(group_reduce_kernel, dim3((n_groups + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles,
+                res->group_sum.as<uint4>());
+        KLAUNCH(scatter_group_kernel, dim3((n_waves + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
+                idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, res->group_sum.as<uint4>(), rd->n_reads + 1,
+                res->hbounds.as<uint32_t>(),
                 res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
                 res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
         kt.end(KT_SCATTER);
@@ -626,11 +634,8 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         HIP_TRY(hipEventSynchronize(res->done));
         const Counters &hc = *res->hc;
         if (hc.fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
-        n_mini = n_hits = 0;
-        for (int i = 0; i < TOTAL_LANES; ++i) {
-            n_mini += hc.totals[0][i];
-            n_hits += hc.totals[2][i];
-        }
+        n_mini = hc.n_mini;
+        n_hits = hc.n_hits;
         if (n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
         bool again = false;
         if (last >= PMAP_STAGE_HITS && n_hits > res->hit_cap) {

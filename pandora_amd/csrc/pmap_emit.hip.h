@@ -20,6 +20,13 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v, uint32_t *total) {
     return incl - v;
 }
 
+// 64-bit sum over the wavefront, valid in every lane
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
 // probe as its own kernel (unfused mode): one wavefront per tile looks up the tile's minimizers
 // (add_read_hits' index->minhash.find, src/utils.cpp:175)
 __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restrict__ mkmer, uint32_t n_tiles,
@@ -43,56 +50,89 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
     if (lane == 0) ((uint32_t *) (tile_cnt + g))[2] = mine;
 }
 
-// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A block of 16 wavefronts takes 1024
-// tiles, a wavefront 64 of them (few, big blocks: the chained prefix sum costs more the more
-// blocks poll each other).  The block's first hit is the chained prefix sum of the blocks'
-// hit counts; batch totals are added to the counters.  A wavefront numbers its entries
-// consecutively (tile by tile, so still in (read, position) order); lane e takes entry e, finds
-// its tile by a search over the per-tile prefix sums held in the lanes, and writes the entry's
-// hits at the running offset + the prefix sum of the record counts.
+// group_sum[G] = {minimizers, entries, hits, 0} of the GROUP_TILES tiles of group G: one wavefront per group
+__global__ __launch_bounds__(256) void group_reduce_kernel(const uint4 *__restrict__ tile_cnt, uint32_t n_tiles,
+                                                           uint4 *__restrict__ group_sum) {
+    const uint32_t lane = threadIdx.x & 63, G = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t t0 = G * GROUP_TILES;
+    if (t0 >= n_tiles) return;
+    uint32_t x = 0, y = 0, z = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < GROUP_TILES / 64; ++i) {
+        const uint32_t t = t0 + i * 64 + lane;
+        if (t < n_tiles) {
+            const uint4 c = tile_cnt[t];
+            x += c.x; y += c.y; z += c.z;
+        }
+    }
+    x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+    if (lane == 0) group_sum[G] = make_uint4(x, y, z, 0);
+}
+
+// Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A wavefront takes SCATTER_TILES tiles.
+// Its first hit = the hit counts of all groups before its own (group_reduce_kernel; summed here by
+// brute force: a few hundred L2-resident words) + the hit counts of the tiles of its own group
+// before its first tile.  No block depends on another one, so the grid is as fine as the
+// latency of a wavefront's dependent loads asks for.  The wavefront numbers its entries
+// consecutively (tile by tile, so still in (read, position) order); lane e takes entry e, finds its
+// tile by a search over the per-tile prefix sums held in the lanes, and writes the entry's hits at
+// the running offset + the prefix sum of the record counts.
 // hbounds[r] = first hit of read r, hbounds[n_reads + r] = ~(one past its last hit); both start as
 // all-ones and are lowered with atomic minima where the read index changes between consecutive
 // entries and at the first and last entry of every wavefront.
-// emit = 0: totals only.
-static const uint32_t SCATTER_WAVES = 16, SCATTER_TILES = 64;   // per block, per wavefront
+// The last wavefront of the grid also folds the batch totals into the counters.
+static const uint32_t SCATTER_TILES = 32;
+static_assert(GROUP_TILES % SCATTER_TILES == 0 && SCATTER_TILES <= 64, "a wavefront stays inside one group");
 
-__global__ __launch_bounds__(1024) void scatter_group_kernel(
+__global__ __launch_bounds__(256) void scatter_group_kernel(
     const uint4 *__restrict__ tile_cnt, uint32_t n_tiles, const uint4 *__restrict__ ents,
     const PmapRec *__restrict__ recs, uint32_t hit_cap, uint32_t emit, Counters *__restrict__ dc,
-    unsigned long long *__restrict__ gran, uint32_t n_reads, uint32_t *__restrict__ hbounds,
-    uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key, uint32_t *__restrict__ h_pos,
-    uint32_t *__restrict__ h_rank, uint32_t *__restrict__ h_rec) {
-    __shared__ uint32_t s_w[SCATTER_WAVES][3];
-    __shared__ uint32_t s_scan[2];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x;
-    const uint32_t t0 = (b * SCATTER_WAVES + wv) * SCATTER_TILES, t = t0 + lane;
+    const uint4 *__restrict__ group_sum, uint32_t n_reads,
+    uint32_t *__restrict__ hbounds, uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key,
+    uint32_t *__restrict__ h_pos, uint32_t *__restrict__ h_rank, uint32_t *__restrict__ h_rec) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t t0 = wave * SCATTER_TILES;
+    if (t0 >= n_tiles) return;
+    const uint32_t G = t0 / GROUP_TILES;
+    // hits before the wavefront's first tile
+    unsigned long long before64 = 0;
+    // 8 independent loads per lane in flight at a time: the sum is latency-bound, not bandwidth-bound
+    for (uint32_t i0 = 0; i0 < G; i0 += 64 * 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u * 64 + lane;
+            v[u] = i < G ? group_sum[i].z : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) before64 += v[u];
+    }
+    for (uint32_t t = G * GROUP_TILES + lane; t < t0; t += 64) before64 += tile_cnt[t].z;
+    uint32_t run = wave_sum((uint32_t) before64);    // offsets are 32-bit: wraps only in a batch the host rejects
+    const uint32_t t = t0 + lane;
     uint4 c = make_uint4(0, 0, 0, 0);
     if (lane < SCATTER_TILES && t < n_tiles) c = tile_cnt[t];
-    const uint32_t n = c.y;
     uint32_t E;
-    const uint32_t estart = wave_scan(n, &E);
-    const uint32_t wmini = wave_sum(c.x), whits = wave_sum(c.z);
-    if (lane == 0) { s_w[wv][0] = wmini; s_w[wv][1] = E; s_w[wv][2] = whits; }
-    __syncthreads();
-    uint32_t bm = 0, be = 0, bh = 0, before = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < SCATTER_WAVES; ++i) {
-        bm += s_w[i][0];
-        be += s_w[i][1];
-        bh += s_w[i][2];
-        if (i < wv) before += s_w[i][2];
+    const uint32_t estart = wave_scan(c.y, &E);
+    if (t0 + SCATTER_TILES >= n_tiles) {
+        // last wavefront: batch totals, in 64 bits, for the kernels that follow and for the host
+        const unsigned long long h = wave_sum64(before64 + c.z);
+        unsigned long long m = 0, en = 0;
+        for (uint32_t i = lane; i <= G; i += 64) {
+            const uint4 gs = group_sum[i];
+            m += gs.x;
+            en += gs.y;
+        }
+        m = wave_sum64(m);
+        en = wave_sum64(en);
+        if (lane == 0) {
+            dc->n_hits = h;
+            dc->n_mini = m;
+            dc->n_ent = en;
+        }
     }
-    if (threadIdx.x < 3) {
-        // spread over 64 words per total: atomics on one word would serialise the blocks
-        const uint32_t v = threadIdx.x == 0 ? bm : threadIdx.x == 1 ? be : bh;
-        if (v) atomicAdd(&dc->totals[threadIdx.x][b % TOTAL_LANES], (unsigned long long) v);
-    }
-    if (!emit) return;
-    const uint32_t excl = chained_scan(gran, b, bh, &dc->fail, s_scan);
-    if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_hits = (unsigned long long) excl + bh;
-    uint32_t run = excl + before;
-    if (E == 0) return;
+    if (!emit || E == 0) return;
     uint32_t *nhend = hbounds + n_reads;
     bool have_prev = false;
     uint32_t prev_r = 0, prev_end = 0;

@@ -282,6 +282,19 @@ __device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots,
     }
 }
 
+// Tiles are summed in groups of GROUP_TILES (group_reduce_kernel) so that the hit emission can find
+// its offsets without a device-wide prefix sum.  (Adding the tile counts to group counters with
+// atomics from this kernel was tried: ~3 atomics per wavefront on words shared by the wavefronts
+// running at the same time tripled the kernel's time.)
+static const uint32_t GROUP_TILES = 256;
+
+struct SketchAux {
+    unsigned long long *state;       // cleared by the first blocks: counters + words of the chained prefix sums
+    uint32_t n_state_words;
+    uint32_t *hbounds;               // set to all-ones by the first blocks
+    uint32_t n_hb;
+};
+
 // FUSED = false: every minimizer of the wavefront goes to its slots of (mkmer, ents).
 // FUSED = true : every minimizer is looked up in the index at once; only those with records go
 //                to the slots of ents; the wavefront's hit count is kept.
@@ -295,15 +308,14 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
     const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
     uint32_t w_arg, uint32_t k, const PmapSlot *__restrict__ slots, uint32_t log2cap,
     const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
-    uint4 *__restrict__ tile_cnt, unsigned long long *__restrict__ state, uint32_t n_state_words,
-    uint32_t *__restrict__ hbounds, uint32_t n_hb) {
+    uint4 *__restrict__ tile_cnt, SketchAux aux) {
     const uint32_t w = WC ? (uint32_t) WC : w_arg;
     // housekeeping for the kernels that follow in the stream, by the first blocks only: zero the
     // counters and the words of the chained prefix sums, set the per-read hit bounds to all-ones
-    if (blockIdx.x * 256u < (n_state_words > n_hb ? n_state_words : n_hb)) {
+    if (blockIdx.x * 256u < (aux.n_state_words > aux.n_hb ? aux.n_state_words : aux.n_hb)) {
         const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-        for (uint32_t i = gid; i < n_state_words; i += gsz) state[i] = 0ull;
-        for (uint32_t i = gid; i < n_hb; i += gsz) hbounds[i] = 0xFFFFFFFFu;
+        for (uint32_t i = gid; i < aux.n_state_words; i += gsz) aux.state[i] = 0ull;
+        for (uint32_t i = gid; i < aux.n_hb; i += gsz) aux.hbounds[i] = 0xFFFFFFFFu;
     }
     __shared__ uint32_t sW[4][SK_NW], sStart[4][SK_NW], sLen[4][SK_NW], sRead[4][SK_NW];
     __shared__ __align__(16) HT sH[4][WAVE_POS];
