@@ -5,7 +5,7 @@
 //   sketch   Seq::minimizer_sketch (src/seq.cpp:91-122) in its closed form: k-mer j of a
 //            read with n k-mers is a minimizer iff some full window [i, i+w) within [0, n)
 //            that contains j has minimum h[j] (every tie kept)
-//   probe    Index::minhash lookup of add_read_hits (src/utils.cpp:174-176): one 16-byte slot per probe
+//   probe    Index::minhash lookup of add_read_hits (src/utils.cpp:174-176): one 32-byte slot (key + first record) per probe
 //   emit     MinimizerHit construction (src/minihit.cpp:14-22): count / prefix sum / scatter
 //   sort     MinimizerHits::sort (src/minihits.cpp:42-53, order src/minihit.cpp:44-66)
 //   cluster  define_clusters (src/utils.cpp:189-249): cut flags, prefix sum, size threshold
@@ -584,7 +584,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     // buffers whose size follows from the batch alone
     const uint32_t n_tiles = res->n_tiles;
     const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS;
-    if ((rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) || (rc = res->ents.ensure(4 * sb)) ||
+    if ((rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) || (rc = res->ents.ensure(8 * sb)) ||
         (rc = res->hbounds.ensure(sizeof(uint32_t) * 2 * ((size_t) rd->n_reads + 1))))
         return rc;
     if (!fused && (rc = res->mkmer.ensure(2 * sb))) return rc;

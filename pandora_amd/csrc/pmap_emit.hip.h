@@ -2,8 +2,8 @@
 // Included by pmap_kernels.hip.h only.
 //
 // The sketch kernel leaves, per wavefront tile g, tile_cnt[g] = {minimizers, entries, hits, 0} and
-// the entries themselves in the tile's 512 slots of `ents`:
-// {read index, position | strand << 31, first record, record count}.
+// the entries themselves in the tile's 512 slots of `ents`, 32 bytes each:
+// {read index, position | strand << 31, first record's index, record count} {the first record}.
 #ifndef PMAP_EMIT_HIP_H
 #define PMAP_EMIT_HIP_H
 
@@ -40,10 +40,12 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
     uint32_t mine = 0;
     for (uint32_t e = lane; e < n; e += 64) {
         uint32_t cnt, off;
-        index_lookup(slots, log2cap, filt, fbits, mkmer[slot0 + e], &cnt, &off);
-        uint32_t *ent = (uint32_t *) (ents + slot0 + e);
+        uint4 first;
+        index_lookup(slots, log2cap, filt, fbits, mkmer[slot0 + e], &cnt, &off, &first);
+        uint32_t *ent = (uint32_t *) (ents + 2 * (slot0 + e));
         ent[2] = off;
         ent[3] = cnt;
+        ents[2 * (slot0 + e) + 1] = first;
         mine += cnt;
     }
     mine = wave_sum(mine);
@@ -147,8 +149,12 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
             if (v <= e) T = cand;
         }
         const uint32_t first = __shfl(estart, T);
-        uint4 ent = make_uint4(0, 0, 0, 0);
-        if (e < E) ent = ents[(uint64_t) (t0 + T) * WAVE_POS + (e - first)];
+        uint4 ent = make_uint4(0, 0, 0, 0), rec0 = make_uint4(0, 0, 0, 0);
+        if (e < E) {
+            const uint4 *slot = ents + 2 * ((uint64_t) (t0 + T) * WAVE_POS + (e - first));
+            ent = slot[0];
+            rec0 = slot[1];
+        }
         const uint32_t cn = ent.w;
         uint32_t tot;
         const uint32_t ho = run + wave_scan(cn, &tot);
@@ -156,7 +162,8 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
         for (uint32_t q = 0; q < cn; ++q) {
             const uint32_t d = ho + q;
             if (d >= hit_cap) break;
-            const uint4 rec = *(const uint4 *) (recs + ent.z + q);   // prg, knode<<1|strand, rank, orig
+            // prg, knode<<1|strand, rank, orig: the first record came with the entry
+            const uint4 rec = q == 0 ? rec0 : *(const uint4 *) (recs + ent.z + q);
             const uint32_t fwd = (strand == (rec.y & 1u));
             h_read[d] = ent.x;
             h_key[d] = rec.x << 1 | (fwd ? 0u : 1u);                 // forward hits sort first (src/minihit.cpp:54-55)
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256) void compact_minimizers_kernel(const uint32_t 
     const uint32_t n = tile_nmini[g], o = tile_moff[g];
     const uint64_t slot0 = (uint64_t) g * WAVE_POS;
     for (uint32_t e = lane; e < n; e += 64) {
-        const uint4 ent = ents[slot0 + e];
+        const uint4 ent = ents[2 * (slot0 + e)];
         o_kmer[o + e] = mkmer[slot0 + e];
         o_read[o + e] = ent.x;
         o_ps[o + e] = ent.y;

@@ -219,12 +219,12 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
     if (log2cap > 31) return pmap_fail(PMAP_ELIMIT, "minimizer table would exceed 2^31 slots");
     idx->log2cap = log2cap;
     const uint32_t cap = 1u << log2cap, capmask = cap - 1;
-    PmapSlot empty{PMAP_EMPTY_KEY, 0, 0};
+    PmapSlot empty{PMAP_EMPTY_KEY, 0, 0, PmapRec{0, 0, 0, 0}};
     idx->slots.assign(cap, empty);
     for (size_t i = 0; i < ukeys.size(); ++i) {
         uint32_t s = pmap_slot_of(ukeys[i], log2cap);
         while (idx->slots[s].key != PMAP_EMPTY_KEY) s = (s + 1) & capmask;
-        idx->slots[s] = PmapSlot{ukeys[i], uoff[i], ucnt[i]};
+        idx->slots[s] = PmapSlot{ukeys[i], uoff[i], ucnt[i], idx->recs[uoff[i]]};
     }
     // presence filter: 8 bits per slot (16 per key at most), at most 2^24 bits (2 MiB) so that it stays
     // in the L2 of every XCD; pointless once the keys would set more than a quarter of the bits
@@ -430,7 +430,7 @@ struct CacheHeader {
     uint64_t src_size, src_mtime_ns, mpl_hash;   // what the cache was built from
 };
 const char CACHE_MAGIC[8] = {'P', 'M', 'A', 'P', 'I', 'D', 'X', '1'};
-const uint32_t CACHE_VERSION = 1;
+const uint32_t CACHE_VERSION = 2;
 
 uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
     const unsigned char *p = (const unsigned char *) data;
@@ -542,7 +542,7 @@ extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out)
     // the file must be exactly as long as the header says, before anything is allocated from it
     uint64_t expect = sizeof(h) + 8;
     const uint64_t sizes[] = {h.n_recs * 8, h.n_recs * 4, h.n_recs * 4, h.n_recs * 4, h.n_recs, (h.n_recs + 1) * 8,
-                              h.n_iv * 4, h.n_iv * 4, (uint64_t) h.n_prg * 4, h.n_slots * 16, h.n_recs * 16,
+                              h.n_iv * 4, h.n_iv * 4, (uint64_t) h.n_prg * 4, h.n_slots * sizeof(PmapSlot), h.n_recs * 16,
                               h.n_filter_words * 4};
     for (uint64_t b : sizes) expect += (b + 63) / 64 * 64;
     struct stat st;
@@ -572,6 +572,7 @@ extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out)
             if (sl.key != PMAP_EMPTY_KEY) {
                 ++used;
                 if ((uint64_t) sl.off + sl.cnt > h.n_recs || sl.cnt == 0) ok = false;
+                else if (memcmp(&sl.first, &idx->recs[sl.off], sizeof(PmapRec)) != 0) ok = false;
             }
         if (used != h.n_keys) ok = false;
         for (const PmapRec &r : idx->recs)

@@ -8,13 +8,6 @@
 
 #include "pandora_amd.h"
 
-// One open-addressing slot of the minimizer table: 16 bytes, one probe = one slot.
-struct PmapSlot {
-    uint64_t key;   // ~0 = empty
-    uint32_t off;   // first record in the CSR array
-    uint32_t cnt;   // number of records
-};
-
 // One CSR record (a MiniRecord, include/minirecord.h:9-14, with the path replaced by its rank).
 struct PmapRec {
     uint32_t prg;
@@ -22,6 +15,18 @@ struct PmapRec {
     uint32_t rank;          // rank of (prg, path) in (prg, prg::Path::operator<) order
     uint32_t orig;          // record index in the caller's arrays
 };
+
+// One open-addressing slot of the minimizer table: 32 bytes, one probe = one slot.  The key's first
+// record rides in the slot: random 16-byte fetches beyond the caches are the scarce resource on a big
+// index (~35 G/s on one MI355X), and nearly every key has a single record, so the hit emission
+// hardly ever has to fetch from the record array.
+struct PmapSlot {
+    uint64_t key;   // ~0 = empty
+    uint32_t off;   // first record in the CSR array
+    uint32_t cnt;   // number of records
+    PmapRec first;  // copy of recs[off]
+};
+static_assert(sizeof(PmapSlot) == 32, "a slot is two 16-byte loads inside one 64-byte sector");
 
 static const uint64_t PMAP_EMPTY_KEY = ~0ULL;
 

@@ -263,9 +263,10 @@ __device__ __forceinline__ Quad<HT> window_max_fwd(const HT *L, int Q, int f, in
 // small enough to stay in L2) turns most absent keys away before the slot table is touched.
 __device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots, uint32_t log2cap,
                                              const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t key,
-                                             uint32_t *cnt, uint32_t *off) {
+                                             uint32_t *cnt, uint32_t *off, uint4 *first) {
     *cnt = 0;
     *off = 0;
+    *first = make_uint4(0, 0, 0, 0);
     const uint32_t hm = pmap_key_mix(key);
     if (fbits) {
         const uint32_t b = hm >> (32 - fbits);
@@ -276,7 +277,13 @@ __device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots,
     for (uint32_t step = 0; step <= capmask; ++step) {   // at most half full: ends at an empty slot
         const uint4 v = *(const uint4 *) (slots + s);
         const uint64_t sk = ((uint64_t) v.y << 32) | v.x;
-        if (sk == key) { *off = v.z; *cnt = v.w; return; }
+        if (sk == key) {
+            // the record half of the slot shares the 64-byte sector that has just been fetched
+            *off = v.z;
+            *cnt = v.w;
+            *first = *((const uint4 *) (slots + s) + 1);
+            return;
+        }
         if (sk == PMAP_EMPTY_KEY) return;
         s = (s + 1) & capmask;
     }
@@ -499,15 +506,17 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
         if (!FUSED) {
             if (e < n) {
                 mkmer[slot0 + e] = (uint64_t) hv;
-                ents[slot0 + e] = make_uint4(rd, ps, 0, 0);
+                ents[2 * (slot0 + e)] = make_uint4(rd, ps, 0, 0);
             }
         } else {
-            if (e < n) index_lookup(slots, log2cap, filt, fbits, (uint64_t) hv, &cnt, &off);
+            uint4 first;
+            if (e < n) index_lookup(slots, log2cap, filt, fbits, (uint64_t) hv, &cnt, &off, &first);
             const unsigned long long b = __ballot(cnt != 0);
             if (cnt) {
                 const uint64_t s = slot0 + nent +
                                    __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
-                ents[s] = make_uint4(rd, ps, off, cnt);
+                ents[2 * s] = make_uint4(rd, ps, off, cnt);
+                ents[2 * s + 1] = first;
             }
             nent += __popcll(b);
             hits += cnt;
