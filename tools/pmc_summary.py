@@ -20,6 +20,7 @@ import os
 import sys
 
 PHASE_OF = [("sketch_wave", "sketch"), ("probe_wave", "probe"), ("scan_", None), ("scatter_group", "probe"),
+            ("group_reduce", "probe"),
             ("sort_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
 
 
