@@ -198,12 +198,10 @@ extern "C" int pmap_index_upload_now(pmap_index_t *idx) {
 void pmap_index_release_device(pmap_index *idx) {
     if (idx->d_slots) (void) hipFree(idx->d_slots);
     if (idx->d_recs) (void) hipFree(idx->d_recs);
-    if (idx->d_thr) (void) hipFree(idx->d_thr);
     if (idx->d_filter) (void) hipFree(idx->d_filter);
     idx->d_filter = nullptr;
     idx->d_slots = nullptr;
     idx->d_recs = nullptr;
-    idx->d_thr = nullptr;
 }
 
 // ---------------------------------------------------------------------------

@@ -65,12 +65,7 @@ struct pmap_index {
     PmapSlot *d_slots = nullptr;
     PmapRec *d_recs = nullptr;
     uint32_t *d_filter = nullptr;
-    uint32_t *d_thr = nullptr;       // per-prg cluster size threshold of the last pmap_map call
     uint64_t device_bytes = 0;
-    // parameters d_thr was computed for
-    float thr_fraction = -1.f;
-    uint32_t thr_min_cluster = 0, thr_expected = 0;
-    bool thr_valid = false;
 };
 
 // pinned host memory (hipHostMalloc), nullptr on failure

@@ -33,19 +33,6 @@ __device__ __forceinline__ uint64_t revcomp_dev(uint64_t fwd, uint32_t k) {
     r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
     return r >> (64 - 2 * k);
 }
-__device__ __forceinline__ uint32_t revcomp_dev(uint32_t fwd, uint32_t k) {
-    uint32_t r = __brev(~fwd);
-    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-    return r >> (32 - 2 * k);
-}
-
-// canonical hash (src/seq.cpp:109-111): h = min(h_fwd, h_rc), strand = (h_fwd <= h_rc)
-template <typename HT>
-__device__ __forceinline__ HT canon_dev(HT fwd, uint32_t k, HT mask, uint32_t *strand) {
-    const HT hf = hash64_dev<HT>(fwd, mask), hr = hash64_dev<HT>(revcomp_dev(fwd, k), mask);
-    *strand = hf <= hr;
-    return hf < hr ? hf : hr;
-}
 
 // exclusive scan of one value per thread over a 256-thread block; *total = block sum
 __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *lds4, uint32_t *total) {

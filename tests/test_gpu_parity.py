@@ -196,3 +196,39 @@ def test_async_batches_in_flight(gpu):
     r = api.map_reads(gidx, reads[3], 14, 15, 250, frac, wait=False)
     r = api.map_reads(gidx, reads[1], 14, 15, 250, frac, result=r, wait=False)
     assert r.counts()["n_hits"] == want[1][0]["n_hits"]
+
+
+def test_random_small_worlds(gpu):
+    """Many small random configurations: w, k, read lengths around the window size and around the
+    tile size (480..512 positions), reads with bad letters, repeated loci, tiny and empty reads."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        k = int(rng.integers(3, 32))
+        w = int(rng.integers(1, 65))
+        n_loci = int(rng.integers(1, 6))
+        loci = [synth.random_dna(int(rng.integers(k + w + 5, 700)), rng) for _ in range(n_loci)]
+        if rng.random() < 0.5:
+            loci.append(loci[0].copy())                      # a duplicated locus: keys with two records
+        si = synth.build_index(loci, w, k, rng=rng, split_paths=float(rng.choice([0.0, 0.3])))
+        reads = []
+        for _ in range(int(rng.integers(1, 30))):
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                r = bytes(synth.random_dna(int(rng.integers(0, w + k + 3)), rng))       # around w+k-1
+            elif kind == 1:
+                r = bytes(synth.random_dna(int(rng.integers(440, 560)), rng))           # around one tile
+            else:
+                l = loci[int(rng.integers(0, len(loci)))]
+                a = int(rng.integers(0, max(1, len(l) - 20)))
+                r = bytes(l[a:a + int(rng.integers(20, 900))])
+                if kind == 2:
+                    r = bytes(synth.revcomp(np.frombuffer(r, np.uint8)))
+                if kind == 3 and len(r) > 5:
+                    p = int(rng.integers(0, len(r)))
+                    r = r[:p] + b"N" + r[p + 1:]
+                if kind == 4:
+                    r = r.lower()
+            reads.append(r)
+        bases, off = O.pack_reads(reads)
+        compare_batch(si, bases, off, w, k, int(rng.integers(1, 300)), api.fraction(float(rng.random()) * 0.2, k),
+                      min_cluster_size=int(rng.integers(0, 4)), first_read_id=int(rng.integers(0, 1000)))
