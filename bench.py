@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--workload", default="nanopore_1k")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--depth", type=int, default=2, help="steps in flight (1 = blocking pmap_map)")
+    ap.add_argument("--depth", type=int, default=3,
+                    help="steps in flight (1 = blocking pmap_map); with 3 the sketch stream never runs dry while the "
+                         "host waits for a result, and the tail kernels of one step run under the sketch kernel of the next")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all inside the timed steps; all kernel times come from the second pass")
     args = ap.parse_args()

@@ -35,7 +35,13 @@
             return pmap_fail(PMAP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr;   // coverage, clearing
+// Two streams carry the map path.  The sketch kernels of successive batches queue up on g_sketch (low
+// priority); everything after the sketch kernel runs on g_tail (high priority) behind an event.  The
+// tail is a string of short, latency-bound kernels that leave most of the GPU idle: this way it runs
+// underneath the VALU-bound sketch kernel of the next batch instead of in front of it.
+static hipStream_t g_sketch = nullptr, g_tail = nullptr;
+static hipStream_t g_cur = nullptr;      // where KLAUNCH enqueues
 static bool g_ready = false;
 
 extern "C" int pmap_init(int device) {
@@ -45,6 +51,12 @@ extern "C" int pmap_init(int device) {
         return pmap_fail(PMAP_EHIP, "no HIP device: libpandora_amd needs an AMD GPU (gfx950), there is no CPU fallback");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_sketch) {
+        int least = 0, greatest = 0;     // numerically lower = higher priority
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&g_sketch, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithPriority(&g_tail, hipStreamNonBlocking, greatest));
+    }
     g_ready = true;
     return PMAP_OK;
 }
@@ -151,6 +163,7 @@ struct pmap_result {
     float thr_fraction = 0;
     uint32_t thr_min = 0, thr_exp = 0;
     hipEvent_t kev[2 * PMAP_N_KERNELS];
+    hipEvent_t sketched = nullptr;    // the sketch kernel of the last enqueued run has finished
     hipEvent_t done = nullptr;        // after the counters of the last enqueued run have reached hc
     bool events = false;
     // a run that was enqueued and not yet waited for
@@ -360,16 +373,16 @@ static KTimer *g_kt = nullptr;
     do {                                                                                                    \
         hipEvent_t s_ = nullptr, e_ = nullptr;                                                              \
         if (g_kt) g_kt->events(&s_, &e_);                                                                   \
-        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(block), 0, g_stream, s_, e_, 0, __VA_ARGS__); \
-        else kernel<<<grid, dim3(block), 0, g_stream>>>(__VA_ARGS__);                                       \
+        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(block), 0, g_cur, s_, e_, 0, __VA_ARGS__);    \
+        else kernel<<<grid, dim3(block), 0, g_cur>>>(__VA_ARGS__);                                          \
     } while (0)
 // (not written in terms of KLAUNCH_B: a second expansion would split template arguments at their commas)
 #define KLAUNCH(kernel, grid, ...)                                                                        \
     do {                                                                                                  \
         hipEvent_t s_ = nullptr, e_ = nullptr;                                                            \
         if (g_kt) g_kt->events(&s_, &e_);                                                                 \
-        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, g_stream, s_, e_, 0, __VA_ARGS__); \
-        else kernel<<<grid, dim3(256), 0, g_stream>>>(__VA_ARGS__);                                       \
+        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, g_cur, s_, e_, 0, __VA_ARGS__);    \
+        else kernel<<<grid, dim3(256), 0, g_cur>>>(__VA_ARGS__);                                          \
     } while (0)
 
 void KTimer::events(hipEvent_t *s, hipEvent_t *e) {
@@ -384,7 +397,7 @@ void KTimer::events(hipEvent_t *s, hipEvent_t *e) {
 template <bool POPC>
 static int device_scan(pmap_result *res, const uint32_t *in, uint32_t *out, uint64_t n, unsigned long long *d_total) {
     if (n == 0) {
-        HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), g_stream));
+        HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), g_cur));
         return PMAP_OK;
     }
     const uint32_t nblk = (uint32_t) ((n + SCAN_TILE - 1) / SCAN_TILE);
@@ -412,6 +425,7 @@ static int run_pipeline(pmap_result *res) {
     const bool fused = res->p_fused;
     const uint32_t last = res->p_last;
     KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
+    g_cur = g_sketch;
     const uint32_t k = prm->k, w = prm->w;
     const bool k32 = k <= 15;
     const uint32_t n_tiles = res->n_tiles;
@@ -428,7 +442,7 @@ static int run_pipeline(pmap_result *res) {
     if (n_tiles == 0) {           // empty batch: nothing to launch
         memset(res->hc, 0, sizeof(Counters));
         res->kt_recorded = 0;
-        HIP_TRY(hipEventRecord(res->done, g_stream));
+        HIP_TRY(hipEventRecord(res->done, g_tail));
         return PMAP_OK;
     }
     // the sketch kernel clears the state block and the read bounds for the kernels after it
@@ -465,6 +479,10 @@ static int run_pipeline(pmap_result *res) {
         kt.end(KT_SKETCH);
         HIP_TRY(hipGetLastError());
     }
+    // everything else follows on the tail stream
+    HIP_TRY(hipEventRecord(res->sketched, g_sketch));
+    HIP_TRY(hipStreamWaitEvent(g_tail, res->sketched, 0));
+    g_cur = g_tail;
 
     // ---- probe (unfused), batch totals, hit emission
     if (n_tiles) {
@@ -517,8 +535,8 @@ static int run_pipeline(pmap_result *res) {
     }
     g_kt = nullptr;
     res->kt_recorded = kt.recorded;
-    HIP_TRY(hipMemcpyAsync(res->hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipEventRecord(res->done, g_stream));
+    HIP_TRY(hipMemcpyAsync(res->hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, g_tail));
+    HIP_TRY(hipEventRecord(res->done, g_tail));
     return PMAP_OK;
 }
 
@@ -559,6 +577,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
         memset(&res->counts, 0, sizeof(res->counts));
         memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
         for (auto &e : res->kev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&res->sketched, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&res->done, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void **) &res->hc, sizeof(Counters), hipHostMallocDefault));
         res->events = true;
@@ -597,8 +616,8 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
                                               prm->min_cluster_size);
         if ((rc = res->thr.ensure(sizeof(uint32_t) * res->thr_host.size()))) return rc;
         HIP_TRY(hipMemcpyAsync(res->thr.p, res->thr_host.data(), sizeof(uint32_t) * res->thr_host.size(),
-                               hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));   // thr_host is pageable and may change before the copy ran
+                               hipMemcpyHostToDevice, g_tail));
+        HIP_TRY(hipStreamSynchronize(g_tail));   // thr_host is pageable and may change before the copy ran
         res->thr_idx = idx;
         res->thr_fraction = prm->fraction;
         res->thr_min = prm->min_cluster_size;
@@ -739,16 +758,17 @@ extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer,
         (rc = ord.ensure(sizeof(uint32_t) * n)) || (rc = ops.ensure(sizeof(uint32_t) * n)) ||
         (rc = res->scratch_total.ensure(sizeof(unsigned long long))))
         return done(rc);
-    hipLaunchKernelGGL(tile_field_kernel, dim3((res->n_tiles + 255) / 256), dim3(256), 0, g_stream,
+    g_cur = g_tail;
+    hipLaunchKernelGGL(tile_field_kernel, dim3((res->n_tiles + 255) / 256), dim3(256), 0, g_cur,
                        res->tile_cnt.as<uint4>(), res->n_tiles, 0u, nmini.as<uint32_t>());
     if ((rc = device_scan<false>(res, nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles,
                                  res->scratch_total.as<unsigned long long>())))
         return done(rc);
-    hipLaunchKernelGGL(compact_minimizers_kernel, dim3((res->n_tiles + 3) / 4), dim3(256), 0, g_stream,
+    hipLaunchKernelGGL(compact_minimizers_kernel, dim3((res->n_tiles + 3) / 4), dim3(256), 0, g_cur,
                        nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles, res->mkmer.as<uint64_t>(),
                        res->ents.as<uint4>(), okm.as<uint64_t>(), ord.as<uint32_t>(),
                        ops.as<uint32_t>());
-    if (hipStreamSynchronize(g_stream) != hipSuccess) return done(pmap_fail(PMAP_EHIP, "minimizer gather failed"));
+    if (hipStreamSynchronize(g_cur) != hipSuccess) return done(pmap_fail(PMAP_EHIP, "minimizer gather failed"));
     if (kmer && hipMemcpy(kmer, okm.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
         return done(pmap_fail(PMAP_EHIP, "copy failed"));
     std::vector<uint32_t> v;
@@ -882,6 +902,7 @@ extern "C" void pmap_result_destroy(pmap_result_t *res) {
     if (res->events) {
         for (auto &e : res->kev) (void) hipEventDestroy(e);
         (void) hipEventDestroy(res->done);
+        (void) hipEventDestroy(res->sketched);
         (void) hipHostFree(res->hc);
     }
     delete res;
