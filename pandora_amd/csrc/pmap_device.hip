@@ -43,6 +43,9 @@ static hipStream_t g_stream = nullptr;   // coverage, clearing
 static hipStream_t g_sketch = nullptr, g_tail = nullptr;
 static hipStream_t g_cur = nullptr;      // where KLAUNCH enqueues
 static bool g_ready = false;
+// PMAP_LDS_WINDOWS=1 in the environment keeps the sketch on the LDS-window kernel where the
+// register-window kernel would be chosen (for comparing the two on a GPU)
+static bool g_lds_windows = false;
 
 extern "C" int pmap_init(int device) {
     int n = 0;
@@ -57,6 +60,8 @@ extern "C" int pmap_init(int device) {
         HIP_TRY(hipStreamCreateWithPriority(&g_sketch, hipStreamNonBlocking, least));
         HIP_TRY(hipStreamCreateWithPriority(&g_tail, hipStreamNonBlocking, greatest));
     }
+    const char *lw = getenv("PMAP_LDS_WINDOWS");
+    g_lds_windows = lw && lw[0] == '1';
     g_ready = true;
     return PMAP_OK;
 }
@@ -469,10 +474,19 @@ static int run_pipeline(pmap_result *res) {
         else if (w == 1) SKETCH_LAUNCH(HT, FUSED, 1);                                                                 \
         else SKETCH_LAUNCH(HT, FUSED, 0);                                                                             \
     } while (0)
-        if (k32 && fused) SKETCH_DISPATCH(uint32_t, true);
+        // k <= 15 with the default w: windows in registers (sketch_dpp_kernel), k = 15 at compile time
+#define SKETCH_DPP(FUSED, WC, KC)                                                                                     \
+    KLAUNCH(HIP_KERNEL_NAME(sketch_dpp_kernel<FUSED, WC, KC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
+        if (k32 && w == 14 && !g_lds_windows) {
+            if (fused && k == 15) SKETCH_DPP(true, 14, 15);
+            else if (fused) SKETCH_DPP(true, 14, 0);
+            else if (k == 15) SKETCH_DPP(false, 14, 15);
+            else SKETCH_DPP(false, 14, 0);
+        } else if (k32 && fused) SKETCH_DISPATCH(uint32_t, true);
         else if (k32) SKETCH_DISPATCH(uint32_t, false);
         else if (fused) SKETCH_DISPATCH(uint64_t, true);
         else SKETCH_DISPATCH(uint64_t, false);
+#undef SKETCH_DPP
 #undef SKETCH_DISPATCH
 #undef SKETCH_LAUNCH
 #undef SKETCH_ARGS

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
             h_rec[d] = rec.w;
         }
         // segment bounds: the entry with hits before this one ends where this one starts
-        const unsigned long long act = __ballot(cn != 0);
+        const unsigned long long act = ballot64(cn != 0);
         if (act) {
             const unsigned long long lower = act & ((1ull << lane) - 1ull);
             const int P = lower ? 63 - __clzll((long long) lower) : 0;

@@ -232,7 +232,7 @@ __device__ __forceinline__ uint32_t chained_scan(unsigned long long *gran, uint3
 #pragma unroll
                 for (int i = 0; i < CHAIN_SLABS; ++i) {
                     if (!done) {
-                        const unsigned long long incl = __ballot((g[i] >> 32) == 2);
+                        const unsigned long long incl = ballot64((g[i] >> 32) == 2);
                         if (incl) {
                             const uint32_t stop = (uint32_t) __builtin_ctzll(incl);   // nearest block that knows its prefix
                             excl += wave_sum(lane <= stop ? (uint32_t) g[i] : 0u);
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(1024) void cluster_cut_kernel(Counters *__restrict_
                 f = s_read[i] != s_read[i - 1] || s_key[i] != s_key[i - 1] || (d < 0 ? -d : d) > max_diff;
             }
         }
-        const unsigned long long m = __ballot(f);
+        const unsigned long long m = ballot64(f);
         rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
         if (f) fbits |= 1u << r;
         if (lane == 0) s_cnt[r * CUT_WAVES + wv] = (uint32_t) __popcll(m);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(1024) void cluster_keep_kernel(Counters *__restrict
         key = s_key[s];
         kept = e - s > thr[key >> 1];
     }
-    const unsigned long long m = __ballot(kept);
+    const unsigned long long m = ballot64(kept);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
     if (lane == 0) s_cnt[wv] = (uint32_t) __popcll(m);
     __syncthreads();
