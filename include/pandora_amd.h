@@ -150,6 +150,12 @@ typedef struct {
  * kernel; hits and clusters are the same either way.  last_stage =
  * PMAP_STAGE_SKETCH implies it. */
 #define PMAP_FLAG_UNFUSED 1u
+/* Diagnostic choice of the sketch kernel for k <= 15, w = 14, where three kernels give the same
+ * results: by default 16 positions per lane with the windows in registers; with these flags 8
+ * positions per lane, or the general kernel (windows through LDS) that serves every other (w, k).
+ * The environment variable PMAP_SKETCH=np8|lds, read by pmap_init, sets the default. */
+#define PMAP_FLAG_SKETCH_NP8 2u
+#define PMAP_FLAG_SKETCH_LDS 4u
 
 /* 0.5 / exp(e_rate * k) as src/utils.cpp:394 evaluates it (float). */
 float pmap_fraction(float e_rate, uint32_t k);

@@ -36,16 +36,23 @@
     } while (0)
 
 static hipStream_t g_stream = nullptr;   // coverage, clearing
-// Two streams carry the map path.  The sketch kernels of successive batches queue up on g_sketch (low
-// priority); everything after the sketch kernel runs on g_tail (high priority) behind an event.  The
-// tail is a string of short, latency-bound kernels that leave most of the GPU idle: this way it runs
-// underneath the VALU-bound sketch kernel of the next batch instead of in front of it.
-static hipStream_t g_sketch = nullptr, g_tail = nullptr;
+// The map path runs on a low-priority sketch stream and a high-priority tail stream.  The sketch
+// kernels of successive batches queue up on the sketch stream; everything after the sketch kernel
+// runs on g_tail behind an event.  The tail is a string of short, latency-bound kernels that leave
+// most of the GPU idle: this way it runs underneath the VALU-bound sketch kernel of the next batch
+// instead of in front of it.  (Alternating the sketch kernels between two streams, so that one
+// fills the compute units the other leaves while it drains, was measured slower: 0.267 against
+// 0.240 ms per step.)
+static const int N_SKETCH_STREAMS = 1;
+static hipStream_t g_sketch[N_SKETCH_STREAMS] = {nullptr}, g_tail = nullptr;
+static unsigned g_sketch_turn = 0;
 static hipStream_t g_cur = nullptr;      // where KLAUNCH enqueues
 static bool g_ready = false;
-// PMAP_LDS_WINDOWS=1 in the environment keeps the sketch on the LDS-window kernel where the
-// register-window kernel would be chosen (for comparing the two on a GPU)
-static bool g_lds_windows = false;
+// Choice of the sketch kernel where the register-window kernel applies (k <= 15, default w), for
+// comparing the variants on a GPU: PMAP_SKETCH=lds keeps the LDS-window kernel, PMAP_SKETCH=np8
+// takes 8 instead of 16 positions per lane (PMAP_FLAG_SKETCH_* do the same per call).
+enum SketchKind { SKETCH_LDS = 0, SKETCH_DPP8 = 8, SKETCH_DPP16 = 16 };
+static SketchKind g_sketch_pref = SKETCH_DPP16;
 
 extern "C" int pmap_init(int device) {
     int n = 0;
@@ -54,14 +61,14 @@ extern "C" int pmap_init(int device) {
         return pmap_fail(PMAP_EHIP, "no HIP device: libpandora_amd needs an AMD GPU (gfx950), there is no CPU fallback");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    if (!g_sketch) {
+    if (!g_tail) {
         int least = 0, greatest = 0;     // numerically lower = higher priority
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&g_sketch, hipStreamNonBlocking, least));
+        for (auto &sk : g_sketch) HIP_TRY(hipStreamCreateWithPriority(&sk, hipStreamNonBlocking, least));
         HIP_TRY(hipStreamCreateWithPriority(&g_tail, hipStreamNonBlocking, greatest));
     }
-    const char *lw = getenv("PMAP_LDS_WINDOWS");
-    g_lds_windows = lw && lw[0] == '1';
+    const char *sk = getenv("PMAP_SKETCH");
+    g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
     g_ready = true;
     return PMAP_OK;
 }
@@ -119,6 +126,28 @@ static_assert(sizeof(Counters) == 64, "Counters is the head of the state block")
 
 #include "pmap_kernels.hip.h"
 
+// the kernel that sketches with (w, k), the output positions of one of its tiles and the slot
+// stride of a tile's outputs
+static SketchKind sketch_kind(uint32_t w, uint32_t k, uint32_t flags, uint32_t *out_pos, uint32_t *stride) {
+    SketchKind kind = g_sketch_pref;
+    if (flags & PMAP_FLAG_SKETCH_LDS) kind = SKETCH_LDS;
+    else if (flags & PMAP_FLAG_SKETCH_NP8) kind = SKETCH_DPP8;
+    if (k > 15 || w != 14) kind = SKETCH_LDS;
+    if (kind == SKETCH_DPP16) {
+        *out_pos = DppTile<16>::OUT;
+        *stride = DppTile<16>::POS;
+    } else if (kind == SKETCH_DPP8) {
+        *out_pos = DppTile<8>::OUT;
+        *stride = DppTile<8>::POS;
+    } else {
+        const uint32_t a = w - 1, edge = (a >> 2) + ((a & 3) ? 1 : 0);
+        *out_pos = 4 * (WAVE_Q - 2 * edge);
+        *stride = WAVE_POS;
+    }
+    return kind;
+}
+
+
 // ---------------------------------------------------------------------------
 // host objects
 
@@ -145,6 +174,7 @@ struct pmap_result {
     pmap_counts_t counts;
     uint32_t first_read_id = 0;
     uint32_t n_tiles = 0;
+    uint32_t tile_stride = 0;          // slot stride of a tile's minimizers / entries (set with n_tiles)
     bool have_minimizers = false;     // the last run kept every minimizer (unfused)
     float kernel_ms[PMAP_N_KERNELS];
     uint32_t hit_cap = 0, cl_cap = 0;
@@ -430,7 +460,8 @@ static int run_pipeline(pmap_result *res) {
     const bool fused = res->p_fused;
     const uint32_t last = res->p_last;
     KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
-    g_cur = g_sketch;
+    hipStream_t sketch_stream = g_sketch[g_sketch_turn++ % N_SKETCH_STREAMS];
+    g_cur = sketch_stream;
     const uint32_t k = prm->k, w = prm->w;
     const bool k32 = k <= 15;
     const uint32_t n_tiles = res->n_tiles;
@@ -475,17 +506,26 @@ static int run_pipeline(pmap_result *res) {
         else SKETCH_LAUNCH(HT, FUSED, 0);                                                                             \
     } while (0)
         // k <= 15 with the default w: windows in registers (sketch_dpp_kernel), k = 15 at compile time
-#define SKETCH_DPP(FUSED, WC, KC)                                                                                     \
-    KLAUNCH(HIP_KERNEL_NAME(sketch_dpp_kernel<FUSED, WC, KC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
-        if (k32 && w == 14 && !g_lds_windows) {
-            if (fused && k == 15) SKETCH_DPP(true, 14, 15);
-            else if (fused) SKETCH_DPP(true, 14, 0);
-            else if (k == 15) SKETCH_DPP(false, 14, 15);
-            else SKETCH_DPP(false, 14, 0);
+#define SKETCH_DPP(FUSED, WC, KC, NP)                                                                                 \
+    KLAUNCH(HIP_KERNEL_NAME(sketch_dpp_kernel<FUSED, WC, KC, NP>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
+#define SKETCH_DPP_NP(NP)                                                                                             \
+    do {                                                                                                              \
+        if (fused && k == 15) SKETCH_DPP(true, 14, 15, NP);                                                           \
+        else if (fused) SKETCH_DPP(true, 14, 0, NP);                                                                  \
+        else if (k == 15) SKETCH_DPP(false, 14, 15, NP);                                                              \
+        else SKETCH_DPP(false, 14, 0, NP);                                                                            \
+    } while (0)
+        uint32_t out_pos_, stride_;
+        const SketchKind kind = sketch_kind(w, k, prm->flags, &out_pos_, &stride_);
+        if (kind == SKETCH_DPP16) {
+            SKETCH_DPP_NP(16);
+        } else if (kind == SKETCH_DPP8) {
+            SKETCH_DPP_NP(8);
         } else if (k32 && fused) SKETCH_DISPATCH(uint32_t, true);
         else if (k32) SKETCH_DISPATCH(uint32_t, false);
         else if (fused) SKETCH_DISPATCH(uint64_t, true);
         else SKETCH_DISPATCH(uint64_t, false);
+#undef SKETCH_DPP_NP
 #undef SKETCH_DPP
 #undef SKETCH_DISPATCH
 #undef SKETCH_LAUNCH
@@ -494,7 +534,7 @@ static int run_pipeline(pmap_result *res) {
         HIP_TRY(hipGetLastError());
     }
     // everything else follows on the tail stream
-    HIP_TRY(hipEventRecord(res->sketched, g_sketch));
+    HIP_TRY(hipEventRecord(res->sketched, sketch_stream));
     HIP_TRY(hipStreamWaitEvent(g_tail, res->sketched, 0));
     g_cur = g_tail;
 
@@ -504,14 +544,16 @@ static int run_pipeline(pmap_result *res) {
         if (!fused && emit) {
             kt.begin(KT_PROBE);
             KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(), n_tiles, idx->d_slots,
-                    idx->log2cap, idx->d_filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>());
+                    idx->log2cap, idx->d_filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>(),
+                    res->tile_stride);
             kt.end(KT_PROBE);
         }
         kt.begin(KT_SCATTER);
         const uint32_t n_waves = (n_tiles + SCATTER_TILES - 1) / SCATTER_TILES;
         KLAUNCH(group_reduce_kernel, dim3((n_groups + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles,
                 res->group_sum.as<uint4>());
-        KLAUNCH(scatter_group_kernel, dim3((n_waves + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles, res->ents.as<uint4>(),
+        KLAUNCH(scatter_group_kernel, dim3((n_waves + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles, res->tile_stride,
+                res->ents.as<uint4>(),
                 idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, res->group_sum.as<uint4>(), rd->n_reads + 1,
                 res->hbounds.as<uint32_t>(),
                 res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
@@ -607,14 +649,15 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     cn.n_bases = rd->n_bases;
     res->first_read_id = rd->first_read_id;
     {
-        const uint32_t a_ = prm->w - 1, edge_ = (a_ >> 2) + ((a_ & 3) ? 1 : 0), out_pos = 4 * (WAVE_Q - 2 * edge_);
+        uint32_t out_pos = 0;
+        sketch_kind(prm->w, prm->k, prm->flags, &out_pos, &res->tile_stride);
         res->n_tiles = (uint32_t) (((uint64_t) rd->n_words * 16 + out_pos - 1) / out_pos);
     }
     res->have_minimizers = false;
 
     // buffers whose size follows from the batch alone
     const uint32_t n_tiles = res->n_tiles;
-    const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * WAVE_POS;
+    const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * res->tile_stride;
     if ((rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) || (rc = res->ents.ensure(8 * sb)) ||
         (rc = res->hbounds.ensure(sizeof(uint32_t) * 2 * ((size_t) rd->n_reads + 1))))
         return rc;
@@ -638,7 +681,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
         res->thr_exp = prm->expected_kmers;
     }
     // capacities of the data-dependent buffers: carried over from earlier calls, grown on overflow
-    if (res->hit_cap == 0 && (rc = ensure_hit_buffers(res, round_up(std::max<uint64_t>(n_tiles * 8ull, 4096), CUT_BLOCK))))
+    if (res->hit_cap == 0 && (rc = ensure_hit_buffers(res, round_up(std::max<uint64_t>((uint64_t) n_tiles * (res->tile_stride / 64), 4096), CUT_BLOCK))))
         return rc;
     if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), KEEP_THREADS))))
         return rc;
@@ -779,7 +822,7 @@ extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer,
                                  res->scratch_total.as<unsigned long long>())))
         return done(rc);
     hipLaunchKernelGGL(compact_minimizers_kernel, dim3((res->n_tiles + 3) / 4), dim3(256), 0, g_cur,
-                       nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles, res->mkmer.as<uint64_t>(),
+                       nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles, res->tile_stride, res->mkmer.as<uint64_t>(),
                        res->ents.as<uint4>(), okm.as<uint64_t>(), ord.as<uint32_t>(),
                        ops.as<uint32_t>());
     if (hipStreamSynchronize(g_cur) != hipSuccess) return done(pmap_fail(PMAP_EHIP, "minimizer gather failed"));

@@ -32,11 +32,12 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restrict__ mkmer, uint32_t n_tiles,
                                                          const PmapSlot *__restrict__ slots, uint32_t log2cap,
                                                          const uint32_t *__restrict__ filt, uint32_t fbits,
-                                                         uint4 *__restrict__ ents, uint4 *__restrict__ tile_cnt) {
+                                                         uint4 *__restrict__ ents, uint4 *__restrict__ tile_cnt,
+                                                         uint32_t stride) {
     const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_tiles) return;
     const uint32_t n = tile_cnt[g].y;
-    const uint64_t slot0 = (uint64_t) g * WAVE_POS;
+    const uint64_t slot0 = (uint64_t) g * stride;
     uint32_t mine = 0;
     for (uint32_t e = lane; e < n; e += 64) {
         uint32_t cnt, off;
@@ -87,7 +88,7 @@ static const uint32_t SCATTER_TILES = 32;
 static_assert(GROUP_TILES % SCATTER_TILES == 0 && SCATTER_TILES <= 64, "a wavefront stays inside one group");
 
 __global__ __launch_bounds__(256) void scatter_group_kernel(
-    const uint4 *__restrict__ tile_cnt, uint32_t n_tiles, const uint4 *__restrict__ ents,
+    const uint4 *__restrict__ tile_cnt, uint32_t n_tiles, uint32_t stride, const uint4 *__restrict__ ents,
     const PmapRec *__restrict__ recs, uint32_t hit_cap, uint32_t emit, Counters *__restrict__ dc,
     const uint4 *__restrict__ group_sum, uint32_t n_reads,
     uint32_t *__restrict__ hbounds, uint32_t *__restrict__ h_read, uint32_t *__restrict__ h_key,
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
         const uint32_t first = __shfl(estart, T);
         uint4 ent = make_uint4(0, 0, 0, 0), rec0 = make_uint4(0, 0, 0, 0);
         if (e < E) {
-            const uint4 *slot = ents + 2 * ((uint64_t) (t0 + T) * WAVE_POS + (e - first));
+            const uint4 *slot = ents + 2 * ((uint64_t) (t0 + T) * stride + (e - first));
             ent = slot[0];
             rec0 = slot[1];
         }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void tile_field_kernel(const uint4 *__restrict
 // gathers the slotted minimizers into one contiguous list (only when a caller asks for them)
 __global__ __launch_bounds__(256) void compact_minimizers_kernel(const uint32_t *__restrict__ tile_nmini,
                                                                  const uint32_t *__restrict__ tile_moff,
-                                                                 uint32_t n_tiles,
+                                                                 uint32_t n_tiles, uint32_t stride,
                                                                  const uint64_t *__restrict__ mkmer,
                                                                  const uint4 *__restrict__ ents,
                                                                  uint64_t *__restrict__ o_kmer,
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void compact_minimizers_kernel(const uint32_t 
     const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_tiles) return;
     const uint32_t n = tile_nmini[g], o = tile_moff[g];
-    const uint64_t slot0 = (uint64_t) g * WAVE_POS;
+    const uint64_t slot0 = (uint64_t) g * stride;
     for (uint32_t e = lane; e < n; e += 64) {
         const uint4 ent = ents[2 * (slot0 + e)];
         o_kmer[o + e] = mkmer[slot0 + e];

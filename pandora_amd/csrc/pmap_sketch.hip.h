@@ -532,22 +532,30 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// k <= 15 and 2 <= w <= 16: the same tile with its windows kept in registers.
+// k <= 15 and 2 <= w <= 16: tiles with their windows kept in registers.
 //
-// Lane l holds the 8 consecutive positions 8l..8l+7 of the wavefront's 512.  A window of w
-// positions is built by doubling: after "v[t] = min(v[t], v[t-S])" with S = 1, 2, 4, ... every
+// Lane l holds NP consecutive positions NP*l .. NP*l + NP-1 of the wavefront's 64 * NP.  A window of
+// w positions is built by doubling: after "v[t] = min(v[t], v[t-S])" with S = 1, 2, 4, ... every
 // v[t] covers 2S positions, and a last step with S = w - (covered) completes it.  No step reaches
 // further back than 8 positions, so the operand is either another register of the lane or a
 // register of the lane before it, taken inside the min / max instruction itself by a DPP
 // whole-wavefront shift (wave_shr:1 / wave_shl:1, full rate on gfx950).  The hashes never go
 // through LDS for the windows: 4 instructions per position for the window minimum and 4 for the
-// window maximum, against ~15 each with LDS quads.
+// window maximum.
 //
 // The tile starts 16 positions before its first output position (a multiple of 16: lane l's
-// bases start at a half-word boundary of packed word l/2) and has 16 halo positions at the end.
+// bases start at a word or half-word boundary of the packed stream) and has 16 halo positions at
+// the end.  NP = 16 halves what is paid per tile (halo, set-up) and fills the 64 lanes of the
+// lookup rounds better (about 132 minimizers in 3 rounds instead of 66 in 2) at 5 instead of 8
+// wavefronts per SIMD.
 static const int DPP_HALO = 16;
-static const int DPP_OUT = WAVE_POS - 2 * DPP_HALO;     // 480 output positions per wavefront
 static const int DPP_MAX_W = 16;
+template <int NP>
+struct DppTile {
+    static const int POS = 64 * NP;                 // positions of a tile = slot stride of its outputs
+    static const int OUT = POS - 2 * DPP_HALO;      // output positions
+    static const int NWD = POS / 16 + 4;            // packed words staged in LDS
+};
 
 // value of x in the lane before / after; `fill` where there is none (lane 0 / lane 63)
 __device__ __forceinline__ uint32_t lane_before(uint32_t x, uint32_t fill) {
@@ -557,56 +565,59 @@ __device__ __forceinline__ uint32_t lane_after(uint32_t x, uint32_t fill) {
     return (uint32_t) __builtin_amdgcn_update_dpp((int) fill, (int) x, 0x130, 0xf, 0xf, false);   // wave_shl:1
 }
 
-// v[t] = min(v[t], v[t - S]) over the wavefront's positions, 1 <= S <= 8
-template <int S>
-__device__ __forceinline__ void slide_min(uint32_t (&v)[8]) {
-    uint32_t o[8];
+// v[t] = min(v[t], v[t - S]) over the wavefront's positions, 1 <= S <= N
+template <int S, int N>
+__device__ __forceinline__ void slide_min(uint32_t (&v)[N]) {
+    uint32_t o[N];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        o[j] = j >= S ? tmin(v[j], v[j >= S ? j - S : 0]) : tmin(v[j], lane_before(v[j >= S ? 0 : 8 - S + j], 0xFFFFFFFFu));
+    for (int j = 0; j < N; ++j)
+        o[j] = j >= S ? tmin(v[j], v[j >= S ? j - S : 0]) : tmin(v[j], lane_before(v[j >= S ? 0 : N - S + j], 0xFFFFFFFFu));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = o[j];
+    for (int j = 0; j < N; ++j) v[j] = o[j];
 }
 // v[t] = max(v[t], v[t + S])
-template <int S>
-__device__ __forceinline__ void slide_max(uint32_t (&v)[8]) {
-    uint32_t o[8];
+template <int S, int N>
+__device__ __forceinline__ void slide_max(uint32_t (&v)[N]) {
+    uint32_t o[N];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        o[j] = j + S < 8 ? tmax(v[j], v[j + S < 8 ? j + S : 0]) : tmax(v[j], lane_after(v[j + S < 8 ? 0 : j + S - 8], 0u));
+    for (int j = 0; j < N; ++j)
+        o[j] = j + S < N ? tmax(v[j], v[j + S < N ? j + S : 0]) : tmax(v[j], lane_after(v[j + S < N ? 0 : j + S - N], 0u));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = o[j];
+    for (int j = 0; j < N; ++j) v[j] = o[j];
 }
 // v[t] = min(v[t-W+1 .. t]); C = positions covered so far
-template <int W, int C = 1>
-__device__ __forceinline__ void window_min8(uint32_t (&v)[8]) {
+template <int W, int N, int C = 1>
+__device__ __forceinline__ void window_min_regs(uint32_t (&v)[N]) {
     if constexpr (2 * C <= W) {
-        slide_min<C>(v);
-        window_min8<W, 2 * C>(v);
+        slide_min<C, N>(v);
+        window_min_regs<W, N, 2 * C>(v);
     } else if constexpr (C < W) {
-        slide_min<W - C>(v);
+        slide_min<W - C, N>(v);
     }
 }
 // v[t] = max(v[t .. t+W-1])
-template <int W, int C = 1>
-__device__ __forceinline__ void window_max8(uint32_t (&v)[8]) {
+template <int W, int N, int C = 1>
+__device__ __forceinline__ void window_max_regs(uint32_t (&v)[N]) {
     if constexpr (2 * C <= W) {
-        slide_max<C>(v);
-        window_max8<W, 2 * C>(v);
+        slide_max<C, N>(v);
+        window_max_regs<W, N, 2 * C>(v);
     } else if constexpr (C < W) {
-        slide_max<W - C>(v);
+        slide_max<W - C, N>(v);
     }
 }
 
-// Same arguments, outputs and tile geometry (for w = 13..16: 480 output positions per wavefront) as
-// sketch_wave_kernel<uint32_t, FUSED, WC>.  KC > 0 fixes k at compile time.
-template <bool FUSED, int WC, int KC>
+// Same arguments and outputs as sketch_wave_kernel<uint32_t, FUSED, WC>; a tile has
+// DppTile<NP>::OUT output positions and its outputs sit at a slot stride of DppTile<NP>::POS.
+// KC > 0 fixes k at compile time.
+template <bool FUSED, int WC, int KC, int NP>
 __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
     uint32_t w_arg, uint32_t k_arg, const PmapSlot *__restrict__ slots, uint32_t log2cap,
     const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
     uint4 *__restrict__ tile_cnt, SketchAux aux) {
-    static_assert(WC >= 2 && WC <= DPP_MAX_W, "window steps must stay within the neighbouring lane");
+    static_assert(WC >= 2 && WC <= DPP_MAX_W && WC - 1 <= DPP_HALO, "window steps must stay within the neighbouring lane");
+    static_assert(NP == 8 || NP == 16, "a lane starts at a word or half-word boundary");
+    typedef DppTile<NP> T;
     (void) w_arg;
     const uint32_t w = WC, k = KC ? (uint32_t) KC : k_arg;
     if (blockIdx.x * 256u < (aux.n_state_words > aux.n_hb ? aux.n_state_words : aux.n_hb)) {
@@ -614,22 +625,24 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
         for (uint32_t i = gid; i < aux.n_state_words; i += gsz) aux.state[i] = 0ull;
         for (uint32_t i = gid; i < aux.n_hb; i += gsz) aux.hbounds[i] = 0xFFFFFFFFu;
     }
-    __shared__ uint32_t sW[4][SK_NW], sStart[4][SK_NW], sLen[4][SK_NW], sRead[4][SK_NW];
-    __shared__ __align__(16) uint32_t sH[4][WAVE_POS];
-    __shared__ uint32_t sList[4][WAVE_POS];
+    __shared__ uint32_t sW[4][T::NWD], sStart[4][T::NWD], sLen[4][T::NWD], sRead[4][T::NWD];
+    __shared__ __align__(16) uint32_t sH[4][T::POS];
+    __shared__ uint16_t sList[4][T::POS];
+    __shared__ uint32_t sStrand[4][64];
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * 4 + wv;
     if (g >= n_tiles) return;
     uint32_t *W = sW[wv], *mstart = sStart[wv], *mlen = sLen[wv], *wr = sRead[wv];
-    uint32_t *h = sH[wv], *list = sList[wv];
+    uint32_t *h = sH[wv], *strands = sStrand[wv];
+    uint16_t *list = sList[wv];
 
     const int a = WC - 1;
-    const int64_t P0 = (int64_t) g * DPP_OUT - DPP_HALO;       // position 0 of the tile, a multiple of 16
+    const int64_t P0 = (int64_t) g * T::OUT - DPP_HALO;        // position 0 of the tile, a multiple of 16
     const int32_t wbase = (int32_t) (P0 >> 4);                  // -1 for g = 0
     const uint32_t P0lo = (uint32_t) P0;
-    if (lane < SK_NW) {
-        const int32_t wi = wbase + lane;
+    for (int t = lane; t < T::NWD; t += 64) {
+        const int32_t wi = wbase + t;
         uint32_t word = 0, ms = 0, ml = 0, ri = 0;
         if (wi >= 0 && wi < (int32_t) n_words) {
             const uint2 wd = words[wi];
@@ -640,32 +653,40 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             ml = rm.y;
             if (ml + 1 < w + k) ml = 0;             // too short to sketch (src/seq.cpp:92-94)
         }
-        W[lane] = word;
-        mstart[lane] = ms;
-        mlen[lane] = ml;
-        wr[lane] = ri;
+        W[t] = word;
+        mstart[t] = ms;
+        mlen[t] = ml;
+        wr[t] = ri;
     }
     wave_lds_sync();
 
-    // ---- canonical hashes of the lane's 8 positions (src/seq.cpp:41-47, 109-111)
+    // ---- canonical hashes of the lane's NP positions (src/seq.cpp:41-47, 109-111)
     const uint32_t mask = (uint32_t) (((uint64_t) 1 << (2 * k)) - 1);
     const HashWidths hw = hash_widths(k);
-    const int wi = lane >> 1;
+    const int wi = NP == 16 ? lane : lane >> 1;
     const uint32_t len = mlen[wi];
-    const uint32_t j0 = P0lo + 8u * (uint32_t) lane - mstart[wi];   // position of the lane's first base inside its read
+    const uint32_t j0 = P0lo + (uint32_t) NP * (uint32_t) lane - mstart[wi];   // position of the lane's first base inside its read
     const int lim = len ? (int) (len - k - j0) : -1;                // k-mer j exists iff j <= lim
     const int lo = a - (int) j0;                                    // its full backward window iff also j >= lo
-    // 24 bases from the lane's first: x0 = 16 of them, the top of x1 the rest (odd lanes start in mid-word)
-    const uint32_t bsel = (lane & 1) ? 0x05040302u : 0x07060504u;
+    // the 32 bases from the lane's first one (NP = 8: odd lanes start in mid-word and only the top
+    // half of x1 is filled, which is as far as their k-mers reach)
     const uint32_t w0 = W[wi], w1 = W[wi + 1];
-    const uint32_t x0 = __builtin_amdgcn_perm(w0, w1, bsel), x1 = __builtin_amdgcn_perm(w1, 0u, bsel);
+    uint32_t x0, x1;
+    if (NP == 16) {
+        x0 = w0;
+        x1 = w1;
+    } else {
+        const uint32_t bsel = (lane & 1) ? 0x05040302u : 0x07060504u;
+        x0 = __builtin_amdgcn_perm(w0, w1, bsel);
+        x1 = __builtin_amdgcn_perm(w1, 0u, bsel);
+    }
     // With Y = reverse complement of the 32 bases x0:x1, the reverse complement of the k-mer at
     // base j is (Y >> 2j) & mask; hash64_u32 ignores what lies above the mask.
     const uint32_t ylo = revcomp16(x0), yhi = revcomp16(x1);
-    uint32_t own[8];
-    uint32_t nstrand = 0;           // bit 7 - j: h_fwd > h_rc at position j, i.e. strand = 0
+    uint32_t own[NP];
+    uint32_t nstrand = 0;           // bit NP-1 - j: h_fwd > h_rc at position j, i.e. strand = 0
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NP; ++j) {
         uint32_t fwd;
         if constexpr (KC > 0) {
             // the k-mer sits 64 - 2k - 2j bits up in x0:x1; one shift brings it down (bits above it do not matter)
@@ -683,67 +704,110 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
         nstrand = __builtin_amdgcn_alignbit(nstrand, hr - hf, 31);   // nstrand << 1 | sign
         own[j] = tmin(hf, hr);
     }
-    *(uint4 *) (h + 8 * lane) = make_uint4(own[0], own[1], own[2], own[3]);
-    *(uint4 *) (h + 8 * lane + 4) = make_uint4(own[4], own[5], own[6], own[7]);
+#pragma unroll
+    for (int q = 0; q < NP / 4; ++q)
+        *(uint4 *) (h + NP * lane + 4 * q) = make_uint4(own[4 * q], own[4 * q + 1], own[4 * q + 2], own[4 * q + 3]);
+    strands[lane] = ~nstrand;
 
     // ---- L[t] = minimum of the full window ending at k-mer t, 0 if that window is not inside one read;
     //      k-mer i is a minimizer iff it equals the largest of the minima of the windows containing it.
     // A wavefront whose every position is a k-mer with its whole backward window inside the read
-    // (the usual case in long reads) needs no masking; lanes 0 and 1 are halo, their windows never count.
-    uint32_t L[8], cmp[8];
+    // (the usual case in long reads) needs no masking; the first 16 positions are halo, their windows never count.
+    uint32_t L[NP], cmp[NP];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) L[j] = cmp[j] = own[j];
-    window_min8<WC>(L);
-    const bool plain = ballot64(lim >= 7) == ~0ull && (ballot64(lo <= 0) | 3ull) == ~0ull;
+    for (int j = 0; j < NP; ++j) L[j] = cmp[j] = own[j];
+    window_min_regs<WC, NP>(L);
+    const unsigned long long HALO_LANES = (1ull << (DPP_HALO / NP)) - 1;
+    const bool plain = ballot64(lim >= NP - 1) == ~0ull && (ballot64(lo <= 0) | HALO_LANES) == ~0ull;
     if (!plain) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NP; ++j) {
             if (j > lim || j < lo) L[j] = 0;
             if (j > lim) cmp[j] = 0xFFFFFFFFu;      // no k-mer here: equals no window minimum (hashes are below 2^30)
         }
     }
-    window_max8<WC>(L);
+    window_max_regs<WC, NP>(L);
 
-    // ---- compaction in position order with ballots: list[e] = index of the e-th minimizer in the
-    // tile (low 9 bits) with its strand in bit 16 (bits 9..15 and above 16 hold leftovers of the shift)
-    const bool inr = (uint32_t) (lane - DPP_HALO / 8) < (uint32_t) (DPP_OUT / 8);
-    const unsigned long long INR_LANES = (~0ull >> (64 - DPP_OUT / 8)) << (DPP_HALO / 8);
+    // ---- compaction in position order with ballots: list[e] = index of the e-th minimizer in the tile
+    const bool inr = (uint32_t) (lane - DPP_HALO / NP) < (uint32_t) (T::OUT / NP);
+    const unsigned long long INR_LANES = (~0ull >> (64 - T::OUT / NP)) << (DPP_HALO / NP);
     uint32_t o = 0, n = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NP; ++j) {
         // (the ballot of a bare comparison is the comparison's own result; the halo lanes go away in scalar code)
         const unsigned long long b = ballot64(L[j] == cmp[j]) & INR_LANES;
         // flags of lower lanes are earlier positions whatever their j
         o += __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
         n += __popcll(b);
     }
-    const uint32_t sbits = ~nstrand, lane8 = 8u * (uint32_t) lane;
+    const uint32_t laneNP = (uint32_t) NP * (uint32_t) lane;
     asm volatile("" : "+v"(o));         // keeps the sum whole: one scaling to a byte offset, not one per term
-    uint32_t *lp = list + o;
+    uint16_t *lp = list + o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (inr && L[j] == cmp[j]) *lp++ = (sbits << (9 + j)) | lane8 | (uint32_t) j;
+    for (int j = 0; j < NP; ++j)
+        if (inr && L[j] == cmp[j]) *lp++ = (uint16_t) (laneNP | (uint32_t) j);
     wave_lds_sync();
 
-    const uint64_t slot0 = (uint64_t) g * WAVE_POS;
+    const uint64_t slot0 = (uint64_t) g * T::POS;
     uint32_t nent = 0, hits = 0;
-    for (uint32_t base = 0; base < n; base += 64) {     // n is wave-uniform
-        const uint32_t e = base + lane;
-        uint32_t cnt = 0, off = 0, ps = 0, rd = 0, hv = 0;
-        if (e < n) {
-            const uint32_t le = list[e], i = le & 0x1FFu, wj = i >> 4;
-            hv = h[i];
-            ps = (P0lo + i - mstart[wj]) | (le >> 16) << 31;     // position inside the read, strand on top
-            rd = wr[wj];
-        }
-        if (!FUSED) {
+    if constexpr (!FUSED) {
+        for (uint32_t base = 0; base < n; base += 64) {     // n is wave-uniform
+            const uint32_t e = base + lane;
             if (e < n) {
-                mkmer[slot0 + e] = (uint64_t) hv;
-                ents[2 * (slot0 + e)] = make_uint4(rd, ps, 0, 0);
+                const uint32_t i = list[e], wj = i >> 4;
+                // strand of position j of a lane: bit NP-1 - j of the lane's word; moved to bit 31
+                const uint32_t st = strands[i / NP] << (32 - NP + (i & (NP - 1)));
+                mkmer[slot0 + e] = (uint64_t) h[i];
+                ents[2 * (slot0 + e)] = make_uint4(wr[wj], (P0lo + i - mstart[wj]) | (st & 0x80000000u), 0, 0);
             }
-        } else {
-            uint4 first;
-            if (e < n) index_lookup(slots, log2cap, filt, fbits, (uint64_t) hv, &cnt, &off, &first);
+        }
+    } else {
+        // ---- presence filter for every minimizer: up to 4 rounds of 64 at a time, their loads in
+        // flight together; what passes stays in the list (compacted in place, position order kept)
+        uint32_t n2 = 0;
+        for (uint32_t base = 0; base < n; base += 256) {
+            uint32_t idx[4], fw[4], fb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                idx[r] = 0;
+                fw[r] = 0;          // lanes past the end pass nothing
+                fb[r] = 0;
+                if (base + 64 * r < n) {
+                    const uint32_t e = base + 64 * r + lane;
+                    if (e < n) {
+                        idx[r] = list[e];
+                        fw[r] = 0xFFFFFFFFu;
+                        if (fbits) {
+                            fb[r] = pmap_key_mix((uint64_t) h[idx[r]]) >> (32 - fbits);
+                            fw[r] = filt[fb[r] >> 5];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (base + 64 * r < n) {
+                    const bool pass = __builtin_amdgcn_ubfe(fw[r], fb[r], 1u) != 0;     // bit fb & 31 of the word
+                    const unsigned long long b = ballot64(pass);
+                    if (pass)
+                        list[n2 + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0))] =
+                            (uint16_t) idx[r];
+                    n2 += __popcll(b);
+                }
+        }
+        wave_lds_sync();
+        // ---- table lookup of those, entries of the ones with records
+        for (uint32_t base = 0; base < n2; base += 64) {
+            const uint32_t e = base + lane;
+            uint32_t cnt = 0, off = 0, ps = 0, rd = 0;
+            uint4 first = make_uint4(0, 0, 0, 0);
+            if (e < n2) {
+                const uint32_t i = list[e], wj = i >> 4;
+                index_lookup(slots, log2cap, nullptr, 0u, (uint64_t) h[i], &cnt, &off, &first);
+                const uint32_t st = strands[i / NP] << (32 - NP + (i & (NP - 1)));
+                ps = (P0lo + i - mstart[wj]) | (st & 0x80000000u);     // position inside the read, strand on top
+                rd = wr[wj];
+            }
             const unsigned long long b = ballot64(cnt != 0);
             if (cnt) {
                 const uint64_t s = slot0 + nent +

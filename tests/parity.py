@@ -57,26 +57,29 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
                        expected_kmers, si.min_path_length)
     assert orc["n_dup_hits"] == 0
 
-    # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
-    res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, unfused=True)
-    cn = res.counts()
-    assert cn["n_minimizers"] == len(orc["mini_kmer"])
-    gm = res.minimizers()
-    so = orc["sketch_off"]
-    oread = np.repeat(ids, np.diff(so).astype(np.int64))
-    np.testing.assert_array_equal(gm["read"], oread)
-    np.testing.assert_array_equal(gm["pos"], orc["mini_pos"])
-    np.testing.assert_array_equal(gm["kmer"], orc["mini_kmer"])
-    np.testing.assert_array_equal(gm["strand"], orc["mini_strand"])
-    _check_hits_and_clusters(res, cn, orc)
-    res.close()
+    # the default sketch kernel and, where (w, k) has more than one, the others
+    for sketch in ((None, "np8", "lds") if (w == 14 and k <= 15) else (None,)):
+        # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
+        res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, unfused=True,
+                            sketch=sketch)
+        cn = res.counts()
+        assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
+        gm = res.minimizers()
+        so = orc["sketch_off"]
+        oread = np.repeat(ids, np.diff(so).astype(np.int64))
+        np.testing.assert_array_equal(gm["read"], oread)
+        np.testing.assert_array_equal(gm["pos"], orc["mini_pos"])
+        np.testing.assert_array_equal(gm["kmer"], orc["mini_kmer"])
+        np.testing.assert_array_equal(gm["strand"], orc["mini_strand"])
+        _check_hits_and_clusters(res, cn, orc)
+        res.close()
 
-    # default (fused) mode
-    res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers)
-    cn = res.counts()
-    assert cn["n_minimizers"] == len(orc["mini_kmer"])
-    _check_hits_and_clusters(res, cn, orc)
-    res.close()
+        # default (fused) mode
+        res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, sketch=sketch)
+        cn = res.counts()
+        assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
+        _check_hits_and_clusters(res, cn, orc)
+        res.close()
     rd.close()
     if own:
         gidx.close()

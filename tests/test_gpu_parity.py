@@ -232,3 +232,37 @@ def test_random_small_worlds(gpu):
         bases, off = O.pack_reads(reads)
         compare_batch(si, bases, off, w, k, int(rng.integers(1, 300)), api.fraction(float(rng.random()) * 0.2, k),
                       min_cluster_size=int(rng.integers(0, 4)), first_read_id=int(rng.integers(0, 1000)))
+
+
+def test_register_window_kernels(gpu):
+    """w = 14 with k <= 15 has three sketch kernels (16 or 8 positions per lane with the windows in
+    registers, and the general one): compare_batch runs all of them.  Read lengths sit around the tile
+    sizes (480 and 992 output positions), around w+k-1, and reads carry bad letters, so that tiles
+    start and end inside, at and between reads in every alignment."""
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        k = int(rng.choice([15, 15, 13, 11, 8, 5]))
+        loci = [synth.random_dna(int(rng.integers(400, 2500)), rng) for _ in range(int(rng.integers(1, 5)))]
+        si = synth.build_index(loci, 14, k, rng=rng, split_paths=float(rng.choice([0.0, 0.3])))
+        reads = []
+        for _ in range(int(rng.integers(1, 40))):
+            kind = int(rng.integers(0, 7))
+            if kind == 0:
+                r = bytes(synth.random_dna(int(rng.integers(0, 14 + k + 3)), rng))
+            elif kind == 1:
+                r = bytes(synth.random_dna(int(rng.choice([480, 992, 1024])) + int(rng.integers(-20, 21)), rng))
+            else:
+                l = loci[int(rng.integers(0, len(loci)))]
+                a = int(rng.integers(0, max(1, len(l) - 30)))
+                r = bytes(l[a:a + int(rng.integers(30, 2400))])
+                if kind == 2:
+                    r = bytes(synth.revcomp(np.frombuffer(r, np.uint8)))
+                if kind == 3 and len(r) > 5:
+                    p = int(rng.integers(0, len(r)))
+                    r = r[:p] + b"N" + r[p + 1:]
+                if kind == 4:
+                    r = r * 2           # the same locus twice in one read
+            reads.append(r)
+        bases, off = O.pack_reads(reads)
+        compare_batch(si, bases, off, 14, k, int(rng.integers(50, 300)), api.fraction(0.11, k),
+                      min_cluster_size=int(rng.integers(0, 4)))
