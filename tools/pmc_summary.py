@@ -19,7 +19,7 @@ import json
 import os
 import sys
 
-PHASE_OF = [("sketch_wave", "sketch"), ("probe_wave", "probe"), ("scan_", None), ("scatter_group", "probe"),
+PHASE_OF = [("sketch_wave", "sketch"), ("sketch_dpp", "sketch"), ("probe_wave", "probe"), ("scan_", None), ("scatter_group", "probe"),
             ("group_reduce", "probe"),
             ("sort_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
 
@@ -83,7 +83,7 @@ def valu(workload, sq_csv, out):
     """SQ_INSTS_VALU (wavefront instructions) per launch of the sketch kernel, merged into out.json"""
     vals = []
     for k, d in per_kernel(sq_csv).items():
-        if "sketch_wave" in k and d.get("SQ_INSTS_VALU"):
+        if ("sketch_wave" in k or "sketch_dpp" in k) and d.get("SQ_INSTS_VALU"):
             vals += d["SQ_INSTS_VALU"]
     cur = json.load(open(out)) if os.path.exists(out) else {}
     cur.setdefault(workload, {})["sketch_valu_insts"] = sum(vals) / max(len(vals), 1)
