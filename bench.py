@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--depth", type=int, default=3,
                     help="steps in flight (1 = blocking pmap_map); with 3 the sketch stream never runs dry while the "
                          "host waits for a result, and the tail kernels of one step run under the sketch kernel of the next")
+    ap.add_argument("--last-stage", type=int, default=0,
+                    help="stop the path after this stage (1 sketch, 2 hits, 3 sort, 4 clusters = all; 0 = all): for "
+                         "experiments, the reported value is then not the metric")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all inside the timed steps; all kernel times come from the second pass")
     args = ap.parse_args()
@@ -164,7 +167,7 @@ def main():
 
     def step(res, profile, wait=True):
         return api.map_reads(gidx, reads, prm["w"], prm["k"], prm["max_diff"], fraction, prm["min_cluster_size"],
-                             expected, profile=profile, result=res, wait=wait)
+                             expected, profile=profile, result=res, wait=wait, last_stage=args.last_stage)
 
     # `depth` result objects take turns, so that the host enqueues a step while the GPU runs the one before
     # (pmap_map_async / pmap_map_wait); depth 1 is the blocking pmap_map
