@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const uint4 *__restri
 // all-ones and are lowered with atomic minima where the read index changes between consecutive
 // entries and at the first and last entry of every wavefront.
 // The last wavefront of the grid also folds the batch totals into the counters.
-static const uint32_t SCATTER_TILES = 32;
+static const uint32_t SCATTER_TILES = 16;
 static_assert(GROUP_TILES % SCATTER_TILES == 0 && SCATTER_TILES <= 64, "a wavefront stays inside one group");
 
 __global__ __launch_bounds__(256) void scatter_group_kernel(
