@@ -64,11 +64,8 @@ extern "C" int pmap_init(int device) {
     if (!g_tail) {
         int least = 0, greatest = 0;     // numerically lower = higher priority
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const char *sm = getenv("PMAP_STREAMS");      // experiment knob: "equal" priorities, or a "single" stream
-        if (sm && !strcmp(sm, "equal")) least = greatest = 0;
         for (auto &sk : g_sketch) HIP_TRY(hipStreamCreateWithPriority(&sk, hipStreamNonBlocking, least));
-        if (sm && !strcmp(sm, "single")) g_tail = g_sketch[0];
-        else HIP_TRY(hipStreamCreateWithPriority(&g_tail, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&g_tail, hipStreamNonBlocking, greatest));
     }
     const char *sk = getenv("PMAP_SKETCH");
     g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
