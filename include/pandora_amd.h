@@ -98,6 +98,8 @@ typedef struct {
     uint32_t k;
     uint64_t n_keys, n_recs, n_paths, table_slots, device_bytes;
     uint32_t n_prg;
+    uint32_t filter_bits;           /* log2 of the size of the presence filter in bits, 0 = none */
+    uint32_t filter_bits_per_key;   /* 1 or 2 (0 without a filter) */
 } pmap_index_info_t;
 int pmap_index_info(const pmap_index_t *idx, pmap_index_info_t *info);
 

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpandora_amd.so")
+# PANDORA_AMD_LIB names another build of the same library (comparing two builds on one GPU box)
+LIB_PATH = os.environ.get("PANDORA_AMD_LIB") or os.path.join(_HERE, "libpandora_amd.so")
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -26,7 +27,8 @@ class IndexDesc(C.Structure):
 
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_uint32), ("n_keys", C.c_uint64), ("n_recs", C.c_uint64), ("n_paths", C.c_uint64),
-                ("table_slots", C.c_uint64), ("device_bytes", C.c_uint64), ("n_prg", C.c_uint32)]
+                ("table_slots", C.c_uint64), ("device_bytes", C.c_uint64), ("n_prg", C.c_uint32),
+                ("filter_bits", C.c_uint32), ("filter_bits_per_key", C.c_uint32)]
 
 
 class Params(C.Structure):

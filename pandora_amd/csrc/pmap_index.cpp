@@ -227,16 +227,23 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         idx->slots[s] = PmapSlot{ukeys[i], uoff[i], ucnt[i], idx->recs[uoff[i]]};
     }
     // presence filter: 8 bits per slot (16 per key at most), at most 2^24 bits (2 MiB) so that it stays
-    // in the L2 of every XCD; pointless once the keys would set more than a quarter of the bits
-    uint32_t fbits = std::min<uint32_t>(log2cap + 3, 24);
+    // in the L2 of every XCD; two bits per key once one bit per key would fill more than 1/16 of it;
+    // pointless once the keys outnumber a quarter of the bits
+    uint32_t max_fbits = 24;
+    if (const char *cap_env = getenv("PMAP_FILTER_MAX_BITS")) {      // tests: every filter mode with a small index
+        const int v = atoi(cap_env);
+        if (v >= 6 && v <= 24) max_fbits = (uint32_t) v;
+    }
+    uint32_t fbits = std::min<uint32_t>(log2cap + 3, max_fbits);
     if (idx->n_keys * 4 > (1ull << fbits)) fbits = 0;
+    else if (idx->n_keys * 16 > (1ull << fbits)) fbits |= PMAP_FILTER_TWO;
     idx->filter_bits = fbits;
     idx->filter.clear();
     if (fbits) {
-        idx->filter.assign((size_t) 1 << (fbits - 5), 0u);
+        idx->filter.assign((size_t) 1 << ((fbits & 0xFFu) - 5), 0u);
         for (size_t i = 0; i < ukeys.size(); ++i) {
-            const uint32_t b = pmap_key_mix(ukeys[i]) >> (32 - fbits);
-            idx->filter[b >> 5] |= 1u << (b & 31);
+            const uint32_t hm = pmap_key_mix(ukeys[i]);
+            idx->filter[pmap_filter_word(hm, fbits)] |= pmap_filter_mask(hm, fbits);
         }
     }
     clk.lap("table + filter");
@@ -430,7 +437,7 @@ struct CacheHeader {
     uint64_t src_size, src_mtime_ns, mpl_hash;   // what the cache was built from
 };
 const char CACHE_MAGIC[8] = {'P', 'M', 'A', 'P', 'I', 'D', 'X', '1'};
-const uint32_t CACHE_VERSION = 2;
+const uint32_t CACHE_VERSION = 3;
 
 uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
     const unsigned char *p = (const unsigned char *) data;
@@ -535,9 +542,10 @@ extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out)
     };
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, CACHE_MAGIC, 8) != 0) return bad("not an index cache");
     if (h.version != CACHE_VERSION) return bad("written by another version");
+    const uint32_t fb = h.filter_bits & 0xFFu;     // number of filter bits; PMAP_FILTER_TWO rides above it
     if (h.k < 1 || h.k > 31 || h.log2cap > 31 || h.n_slots != (1ull << h.log2cap) || h.n_recs >= 0xFFFFFFFFull ||
-        h.n_keys > h.n_recs || h.filter_bits > 24 ||
-        h.n_filter_words != (h.filter_bits ? (1ull << (h.filter_bits - 5)) : 0))
+        h.n_keys > h.n_recs || (h.filter_bits & ~(0xFFu | PMAP_FILTER_TWO)) || fb > 24 || (fb && fb < 6) ||
+        (!fb && h.filter_bits) || h.n_filter_words != (fb ? (1ull << (fb - 5)) : 0))
         return bad("inconsistent header");
     // the file must be exactly as long as the header says, before anything is allocated from it
     uint64_t expect = sizeof(h) + 8;
@@ -654,6 +662,8 @@ extern "C" int pmap_index_info(const pmap_index_t *idx, pmap_index_info_t *info)
     info->table_slots = idx->slots.size();
     info->device_bytes = idx->device_bytes;
     info->n_prg = idx->n_prg;
+    info->filter_bits = idx->filter_bits & 0xFFu;
+    info->filter_bits_per_key = !idx->filter_bits ? 0u : (idx->filter_bits & PMAP_FILTER_TWO) ? 2u : 1u;
     return PMAP_OK;
 }
 

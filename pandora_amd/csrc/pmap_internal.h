@@ -42,6 +42,16 @@ PMAP_HD static inline uint32_t pmap_key_mix(uint64_t key) {
 PMAP_HD static inline uint32_t pmap_slot_of(uint64_t key, uint32_t log2cap) {
     return pmap_key_mix(key) >> (32 - log2cap);
 }
+// Presence filter over hm = pmap_key_mix(key).  `fb` = number of bits of the filter (its low byte,
+// 0 = no filter), with PMAP_FILTER_TWO when every key sets two bits of its 32-bit word instead of
+// one (denser indexes: the false-positive rate is about the square of the fill instead of the fill).
+static const uint32_t PMAP_FILTER_TWO = 0x100u;
+PMAP_HD static inline uint32_t pmap_filter_word(uint32_t hm, uint32_t fb) { return hm >> (32 - (fb & 0xFFu)) >> 5; }
+PMAP_HD static inline uint32_t pmap_filter_mask(uint32_t hm, uint32_t fb) {
+    uint32_t m = 1u << ((hm >> (32 - (fb & 0xFFu))) & 31u);
+    if (fb & PMAP_FILTER_TWO) m |= 1u << ((hm >> 3) & 31u);      // hash bits the word index does not use
+    return m;
+}
 
 struct pmap_index {
     uint32_t k = 0;
@@ -58,7 +68,7 @@ struct pmap_index {
     // host copies of the device structures (kept for checks and rebuilds)
     std::vector<PmapSlot> slots;
     std::vector<PmapRec> recs;
-    // presence filter: bit (pmap_key_mix(key) >> (32 - filter_bits)) is set for every key; 0 bits = no filter
+    // presence filter: pmap_filter_mask(key) is set in word pmap_filter_word(key) for every key; 0 = no filter
     uint32_t filter_bits = 0;
     std::vector<uint32_t> filter;
     // device

@@ -263,8 +263,9 @@ __device__ __forceinline__ Quad<HT> window_max_fwd(const HT *L, int Q, int f, in
     return out;
 }
 
-// One lookup of the index: the presence filter (one bit per 2^-fbits of the home-slot hash range,
-// small enough to stay in L2) turns most absent keys away before the slot table is touched.
+// One lookup of the index: the presence filter (pmap_filter_word / pmap_filter_mask: one or two bits
+// per key in a bitmap small enough to stay in L2) turns most absent keys away before the slot table
+// is touched.
 __device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots, uint32_t log2cap,
                                              const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t key,
                                              uint32_t *cnt, uint32_t *off, uint4 *first) {
@@ -273,8 +274,8 @@ __device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots,
     *first = make_uint4(0, 0, 0, 0);
     const uint32_t hm = pmap_key_mix(key);
     if (fbits) {
-        const uint32_t b = hm >> (32 - fbits);
-        if (!((filt[b >> 5] >> (b & 31)) & 1u)) return;
+        const uint32_t m = pmap_filter_mask(hm, fbits);
+        if ((filt[pmap_filter_word(hm, fbits)] & m) != m) return;
     }
     const uint32_t capmask = (1u << log2cap) - 1;
     uint32_t s = hm >> (32 - log2cap);
@@ -766,19 +767,22 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
         // flight together; what passes stays in the list (compacted in place, position order kept)
         uint32_t n2 = 0;
         for (uint32_t base = 0; base < n; base += 256) {
-            uint32_t idx[4], fw[4], fb[4];
+            uint32_t idx[4], fw[4], fb[4], fb2[4];
+            const uint32_t fsh = (32 - (fbits & 0xFFu)) & 31u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 idx[r] = 0;
                 fw[r] = 0;          // lanes past the end pass nothing
-                fb[r] = 0;
+                fb[r] = fb2[r] = 0;
                 if (base + 64 * r < n) {
                     const uint32_t e = base + 64 * r + lane;
                     if (e < n) {
                         idx[r] = list[e];
                         fw[r] = 0xFFFFFFFFu;
                         if (fbits) {
-                            fb[r] = pmap_key_mix((uint64_t) h[idx[r]]) >> (32 - fbits);
+                            const uint32_t hm = pmap_key_mix((uint64_t) h[idx[r]]);
+                            fb[r] = hm >> fsh;                                  // pmap_filter_word / pmap_filter_mask
+                            if (fbits & PMAP_FILTER_TWO) fb2[r] = hm >> 3;
                             fw[r] = filt[fb[r] >> 5];
                         }
                     }
@@ -787,7 +791,10 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (base + 64 * r < n) {
-                    const bool pass = __builtin_amdgcn_ubfe(fw[r], fb[r], 1u) != 0;     // bit fb & 31 of the word
+                    // bit fb & 31 of the word and, with two bits per key, bit fb2 & 31 as well
+                    uint32_t t = __builtin_amdgcn_ubfe(fw[r], fb[r], 1u);
+                    if (fbits & PMAP_FILTER_TWO) t &= fw[r] >> (fb2[r] & 31u);
+                    const bool pass = t != 0;
                     const unsigned long long b = ballot64(pass);
                     if (pass)
                         list[n2 + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0))] =

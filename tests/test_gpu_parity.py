@@ -286,3 +286,20 @@ def test_sort_segment_sizes(gpu):
     cn, orc = compare_batch(si, bases, off, 14, 15, 250, api.fraction(0.11, 15), min_cluster_size=2)
     per_read = np.bincount(orc["hit_read"], minlength=len(reads))
     assert per_read.max() > 1024 and (per_read < 24).any() and ((per_read > 512) & (per_read <= 1024)).any()
+
+
+def test_presence_filter_modes(gpu, monkeypatch):
+    """The presence filter in front of the table has one bit per key, two bits per key (dense indexes)
+    or is absent (very dense ones).  PMAP_FILTER_MAX_BITS shrinks it so that a small index reaches every
+    mode; results must not depend on it."""
+    si, bases, off = _small_world(31, 14, 15, n_loci=12, n_reads=40)
+    seen = set()
+    for max_bits in ("24", "16", "14", "12"):
+        monkeypatch.setenv("PMAP_FILTER_MAX_BITS", max_bits)
+        gidx = gpu_index(si)
+        info = gidx.info()
+        seen.add(info["filter_bits_per_key"])
+        compare_batch(si, bases, off, 14, 15, 250, api.fraction(0.11, 15), gidx=gidx)
+        compare_batch(si, bases, off, 9, 15, 250, api.fraction(0.11, 15), gidx=gidx)     # general sketch kernel
+        gidx.close()
+    assert seen == {0, 1, 2}, seen
