@@ -467,7 +467,7 @@ static int run_pipeline(pmap_result *res) {
     const uint32_t n_tiles = res->n_tiles;
     // state block: counters + one 8-byte word per block of each chained prefix sum
     res->n_ablk = res->hit_cap / CUT_BLOCK;
-    res->n_bblk = res->cl_cap / KEEP_THREADS;
+    res->n_bblk = res->cl_cap / KEEP_BLOCK;
     const size_t state_bytes =
         (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
     if ((rc = res->state.ensure(state_bytes))) return rc;
@@ -683,7 +683,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     // capacities of the data-dependent buffers: carried over from earlier calls, grown on overflow
     if (res->hit_cap == 0 && (rc = ensure_hit_buffers(res, round_up(std::max<uint64_t>((uint64_t) n_tiles * (res->tile_stride / 64), 4096), CUT_BLOCK))))
         return rc;
-    if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), KEEP_THREADS))))
+    if (res->cl_cap == 0 && (rc = ensure_cluster_buffers(res, round_up(std::max<uint64_t>(res->hit_cap / 8, 1024), KEEP_BLOCK))))
         return rc;
 
     res->p_idx = idx;
@@ -719,7 +719,7 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         // at most one cluster per hit; when the hits overflowed the cluster count is only a lower bound
         if (last >= PMAP_STAGE_CLUSTER && (hc.n_cl > res->cl_cap || (again && res->cl_cap < res->hit_cap / 8))) {
             const uint64_t want = std::max<uint64_t>(hc.n_cl + hc.n_cl / 8, res->hit_cap / 8);
-            if ((rc = ensure_cluster_buffers(res, round_up(std::min<uint64_t>(want, res->hit_cap), KEEP_THREADS)))) return rc;
+            if ((rc = ensure_cluster_buffers(res, round_up(std::min<uint64_t>(want, res->hit_cap), KEEP_BLOCK)))) return rc;
             again = true;
         }
         if (!again) break;

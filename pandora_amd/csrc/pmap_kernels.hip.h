@@ -321,23 +321,28 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
 }
 
 // ---------------------------------------------------------------------------
-// cluster cut (src/utils.cpp:206-209).  A block of 1024 threads takes 8192 sorted hits (8 rounds of
-// 1024), flags the hits that start a cluster, and writes their indices to cstart at the chained
-// prefix sum of the blocks' flag counts.  The last block writes the cluster total.  Big blocks keep
-// the chain short: its cost grows with the number of blocks that poll each other's words.
-static const uint32_t CUT_THREADS = 1024, CUT_WAVES = CUT_THREADS / 64, CUT_ROUNDS = 8, CUT_BLOCK = CUT_THREADS * CUT_ROUNDS;
+// cluster cut (src/utils.cpp:206-209).  A block of 512 threads takes 8192 sorted hits (16 rounds of
+// 512), flags the hits that start a cluster, and writes their indices to cstart at the chained
+// prefix sum of the blocks' flag counts.  The last block writes the cluster total.  Many hits per
+// block keep the chain short (its cost grows with the number of blocks that poll each other's
+// words).  8 wavefronts per block: a 1024-thread block needs 4 free slots on every SIMD of a
+// compute unit at once, and next to a long kernel of small blocks (the sketch of the next batch,
+// which leaves 3) it could not start before that kernel had drained: 136 instead of 11 us.
+static const uint32_t CUT_THREADS = 512, CUT_WAVES = CUT_THREADS / 64, CUT_ROUNDS = 16, CUT_BLOCK = CUT_THREADS * CUT_ROUNDS;
 
-__global__ __launch_bounds__(1024) void cluster_cut_kernel(Counters *__restrict__ dc, uint32_t hit_cap,
-                                                           const uint32_t *__restrict__ s_read,
-                                                           const uint32_t *__restrict__ s_key,
-                                                           const uint32_t *__restrict__ s_pos, int max_diff,
-                                                           unsigned long long *__restrict__ gran, uint32_t cl_cap,
-                                                           uint32_t *__restrict__ cstart) {
+__global__ __launch_bounds__(CUT_THREADS) void cluster_cut_kernel(Counters *__restrict__ dc, uint32_t hit_cap,
+                                                                  const uint32_t *__restrict__ s_read,
+                                                                  const uint32_t *__restrict__ s_key,
+                                                                  const uint32_t *__restrict__ s_pos, int max_diff,
+                                                                  unsigned long long *__restrict__ gran,
+                                                                  uint32_t cl_cap, uint32_t *__restrict__ cstart) {
     __shared__ uint32_t s_cnt[CUT_ROUNDS * CUT_WAVES], s_half[2], s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
-    uint32_t fbits = 0, rank[CUT_ROUNDS];
+    uint32_t fbits = 0;
+    uint8_t rank[CUT_ROUNDS];
+    static_assert(CUT_ROUNDS <= 32, "one flag bit per round");
 #pragma unroll
     for (uint32_t r = 0; r < CUT_ROUNDS; ++r) {
         const uint32_t i = b * CUT_BLOCK + r * CUT_THREADS + threadIdx.x;
@@ -350,13 +355,13 @@ __global__ __launch_bounds__(1024) void cluster_cut_kernel(Counters *__restrict_
             }
         }
         const unsigned long long m = ballot64(f);
-        rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
+        rank[r] = (uint8_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
         if (f) fbits |= 1u << r;
         if (lane == 0) s_cnt[r * CUT_WAVES + wv] = (uint32_t) __popcll(m);
     }
     __syncthreads();
     // exclusive scan of the 128 (round, wavefront) counts, which are in hit order, by wavefronts 0 and 1
-    static_assert(CUT_ROUNDS * CUT_WAVES == 128, "two wavefronts scan the counts");
+    static_assert(CUT_ROUNDS * CUT_WAVES == 128 && CUT_WAVES >= 2, "two wavefronts scan the counts");
     uint32_t ex = 0;
     if (wv < 2) {
         uint32_t tot;
@@ -376,50 +381,61 @@ __global__ __launch_bounds__(1024) void cluster_cut_kernel(Counters *__restrict_
     if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_cl = (unsigned long long) excl + total;
 }
 
-// One thread per cluster, blocks of 1024: size threshold (src/utils.cpp:211-220) and, for the
-// clusters kept, the summary row {first hit, size, read, prg << 1 | !forward, first position, last
-// position, path rank of the first hit, cluster number} at the chained prefix sum of the kept
-// counts.  The last block writes the kept total.
-static const uint32_t KEEP_THREADS = 1024, KEEP_WAVES = KEEP_THREADS / 64;
+// One thread per cluster, 2 rounds of 512 per block: size threshold (src/utils.cpp:211-220) and,
+// for the clusters kept, the summary row {first hit, size, read, prg << 1 | !forward, first
+// position, last position, path rank of the first hit, cluster number} at the chained prefix sum of
+// the kept counts.  The last block writes the kept total.
+static const uint32_t KEEP_THREADS = 512, KEEP_WAVES = KEEP_THREADS / 64, KEEP_ROUNDS = 2, KEEP_BLOCK = KEEP_THREADS * KEEP_ROUNDS;
 
-__global__ __launch_bounds__(1024) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
-                                                            uint32_t hit_cap, const uint32_t *__restrict__ cstart,
-                                                            const uint32_t *__restrict__ s_read,
-                                                            const uint32_t *__restrict__ s_key,
-                                                            const uint32_t *__restrict__ s_pos,
-                                                            const uint32_t *__restrict__ s_rank,
-                                                            const uint32_t *__restrict__ thr,
-                                                            unsigned long long *__restrict__ gran,
-                                                            uint32_t *__restrict__ k_rows) {
-    __shared__ uint32_t s_cnt[KEEP_WAVES], s_scan[2];
+__global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
+                                                                    uint32_t hit_cap, const uint32_t *__restrict__ cstart,
+                                                                    const uint32_t *__restrict__ s_read,
+                                                                    const uint32_t *__restrict__ s_key,
+                                                                    const uint32_t *__restrict__ s_pos,
+                                                                    const uint32_t *__restrict__ s_rank,
+                                                                    const uint32_t *__restrict__ thr,
+                                                                    unsigned long long *__restrict__ gran,
+                                                                    uint32_t *__restrict__ k_rows) {
+    __shared__ uint32_t s_cnt[KEEP_ROUNDS * KEEP_WAVES], s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n_cl = clamp_count(&dc->n_cl, cl_cap), n_hits = clamp_count(&dc->n_hits, hit_cap);
-    const uint32_t c = b * KEEP_THREADS + threadIdx.x;
-    bool kept = false;
-    uint32_t s = 0, e = 0, key = 0;
-    if (c < n_cl) {
-        s = cstart[c];
-        e = c + 1 < n_cl ? cstart[c + 1] : n_hits;
-        key = s_key[s];
-        kept = e - s > thr[key >> 1];
-    }
-    const unsigned long long m = ballot64(kept);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
-    if (lane == 0) s_cnt[wv] = (uint32_t) __popcll(m);
-    __syncthreads();
-    uint32_t total = 0, before = 0;
+    bool kept[KEEP_ROUNDS];
+    uint32_t s[KEEP_ROUNDS], e[KEEP_ROUNDS], key[KEEP_ROUNDS], rank[KEEP_ROUNDS];
 #pragma unroll
-    for (uint32_t v = 0; v < KEEP_WAVES; ++v) {
-        if (v == wv) before = total;
+    for (uint32_t r = 0; r < KEEP_ROUNDS; ++r) {
+        const uint32_t c = b * KEEP_BLOCK + r * KEEP_THREADS + threadIdx.x;
+        kept[r] = false;
+        s[r] = e[r] = key[r] = 0;
+        if (c < n_cl) {
+            s[r] = cstart[c];
+            e[r] = c + 1 < n_cl ? cstart[c + 1] : n_hits;
+            key[r] = s_key[s[r]];
+            kept[r] = e[r] - s[r] > thr[key[r] >> 1];
+        }
+        const unsigned long long m = ballot64(kept[r]);
+        rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
+        if (lane == 0) s_cnt[r * KEEP_WAVES + wv] = (uint32_t) __popcll(m);
+    }
+    __syncthreads();
+    // (round, wavefront) counts are in cluster order
+    uint32_t total = 0, before[KEEP_ROUNDS];
+#pragma unroll
+    for (uint32_t v = 0; v < KEEP_ROUNDS * KEEP_WAVES; ++v) {
+#pragma unroll
+        for (uint32_t r = 0; r < KEEP_ROUNDS; ++r)
+            if (v == r * KEEP_WAVES + wv) before[r] = total;
         total += s_cnt[v];
     }
     const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);
-    if (kept) {
-        uint32_t *row = k_rows + (uint64_t) (excl + before + rank) * 8;
-        *(uint4 *) row = make_uint4(s, e - s, s_read[s], key);
-        *(uint4 *) (row + 4) = make_uint4(s_pos[s], s_pos[e - 1], s_rank[s], c);
-    }
+#pragma unroll
+    for (uint32_t r = 0; r < KEEP_ROUNDS; ++r)
+        if (kept[r]) {
+            const uint32_t c = b * KEEP_BLOCK + r * KEEP_THREADS + threadIdx.x;
+            uint32_t *row = k_rows + (uint64_t) (excl + before[r] + rank[r]) * 8;
+            *(uint4 *) row = make_uint4(s[r], e[r] - s[r], s_read[s[r]], key[r]);
+            *(uint4 *) (row + 4) = make_uint4(s_pos[s[r]], s_pos[e[r] - 1], s_rank[s[r]], c);
+        }
     if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_kept = (unsigned long long) excl + total;
 }
 
