@@ -207,6 +207,7 @@ def main():
             retire(j)
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     res = ring[(args.steps - 1) % depth] if args.steps else ring[0]
     cn = res.counts()
     # second, untimed pass with events on every kernel, for the per-phase table
@@ -264,6 +265,11 @@ def main():
             alone = sketch_alone_ms / steps
             roofline["ms_per_launch_alone"] = alone
             roofline["achieved_alone"] = algo[dom] / (alone * 1e-3) / 1e9
+            if prof:
+                # the library alternates the sketch kernels of successive steps between two streams: launches
+                # overlap, each lasts longer than it would alone, and together they move this many bytes per second
+                roofline["launches_in_flight"] = sketch_ms / (elapsed_local * 1e3)
+                roofline["achieved_all_launches"] = algo[dom] * args.steps / elapsed_local / 1e9
             if valu:
                 valu["frac_alone"] = valu["wave_insts_per_launch"] / (alone * 1e-3) / valu["peak_insts_per_s"]
         out = {
