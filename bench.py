@@ -22,6 +22,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
+# The library keeps four streams busy (two for sketch kernels, one for everything after them, one for
+# uploads); torch and the collective library bring their own.  With the HIP default of 4 hardware queues
+# per process the two sketch streams then end up on one queue and stop overlapping (measured: 433 instead
+# of 463 Gbases/s once the process group exists).  Read by the HIP runtime when it starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # kernels of each phase (names of pmap_kernel_name)
 PHASES = {
     "sketch": ["sketch"],          # fused mode: the index lookup runs inside this kernel
@@ -118,8 +124,10 @@ def cpu_baseline(si, bases, offsets, prm, fraction, budget_s=10.0, threads_budge
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (a step takes a quarter of a millisecond: a few hundred of them make the "
+                         "barrier and synchronisation at both ends of the timed region negligible)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="nanopore_1k")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,9 +141,22 @@ def main():
                     help="no HIP events at all inside the timed steps; all kernel times come from the second pass")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: whatever libraries print there while they start up
+    # (the collective library prints a version banner) goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    if os.environ.get("PANDORA_BENCH_WATCHDOG"):
+        # dumps every thread's Python stack to stderr if the run is still going after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PANDORA_BENCH_WATCHDOG"]), exit=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # PANDORA_BENCH_FORCE_DIST=1: go through torch.distributed (process group, barriers, reductions) even with one
+    # rank, to see on a one-GPU box what the collective library's streams do to the timing of the N > 1 runs
+    use_dist = world > 1 or os.environ.get("PANDORA_BENCH_FORCE_DIST") == "1"
 
     import torch
     import torch.distributed as dist
@@ -143,7 +164,7 @@ def main():
     backend = os.environ.get("PANDORA_BENCH_BACKEND", "nccl")
     device = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(device)
-    if world > 1:
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -178,7 +199,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[device]) if backend == "nccl" else dist.barrier()
 
     kernel_ms, sketch_ms = {}, 0.0
@@ -224,7 +245,7 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([float(cn["n_bases"]), float(cn["n_hits"])], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -303,8 +324,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(si, bases, offsets, prm, fraction)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier(device_ids=[device]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 

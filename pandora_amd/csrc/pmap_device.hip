@@ -36,7 +36,7 @@
     } while (0)
 
 static hipStream_t g_stream = nullptr;   // coverage, clearing: an alias of g_tail
-// The map path runs on two low-priority sketch streams and a high-priority tail stream.  The sketch
+// The map path runs on two sketch streams and a tail stream.  The sketch
 // kernels of successive batches alternate between the sketch streams (they do not depend on each
 // other): the second one fills the compute units as the first one drains, and the 15 us between two
 // kernels of one stream (end-of-kernel barrier, event, launch) are hidden behind the other stream.
@@ -64,10 +64,10 @@ extern "C" int pmap_init(int device) {
         return pmap_fail(PMAP_EHIP, "no HIP device: libpandora_amd needs an AMD GPU (gfx950), there is no CPU fallback");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     if (!g_tail) {
-        int least = 0, greatest = 0;     // numerically lower = higher priority
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (auto &sk : g_sketch) HIP_TRY(hipStreamCreateWithPriority(&sk, hipStreamNonBlocking, least));
-        HIP_TRY(hipStreamCreateWithPriority(&g_tail, hipStreamNonBlocking, greatest));
+        // all at the default priority: priorities made no difference to the timing, and with two processes
+        // on one GPU a low-priority sketch queue that the tail queue waits for was never scheduled
+        for (auto &sk : g_sketch) HIP_TRY(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&g_tail, hipStreamNonBlocking));
         g_stream = g_tail;
     }
     const char *sk = getenv("PMAP_SKETCH");
