@@ -158,6 +158,9 @@ typedef struct {
  * The environment variable PMAP_SKETCH=np8|lds, read by pmap_init, sets the default. */
 #define PMAP_FLAG_SKETCH_NP8 2u
 #define PMAP_FLAG_SKETCH_LDS 4u
+/* Diagnostic: sort with the kernel variant for indexes of more than 2^19 loci (keys too wide to share a
+ * word with a position) whatever the index. */
+#define PMAP_FLAG_SORT_WIDE 8u
 
 /* 0.5 / exp(e_rate * k) as src/utils.cpp:394 evaluates it (float). */
 float pmap_fraction(float e_rate, uint32_t k);

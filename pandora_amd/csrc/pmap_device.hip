@@ -568,12 +568,17 @@ static int run_pipeline(pmap_result *res) {
     // ---- sort
     if (last >= PMAP_STAGE_SORT && n_tiles) {
         kt.begin(KT_SORT);
-        KLAUNCH(sort_rank_kernel, dim3(res->hit_cap / 256), &dc->n_hits,
-                           res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(),
-                           res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(),
-                           res->hbounds.as<uint32_t>(), rd->n_reads + 1, res->s_read.as<uint32_t>(),
-                           res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(),
-                           res->s_rec.as<uint32_t>());
+#define SORT_ARGS                                                                                                     \
+    &dc->n_hits, res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),      \
+        res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,          \
+        res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), \
+        res->s_rec.as<uint32_t>()
+        // keys are prg << 1 | strand: narrow enough to share a word with a place in the staged chunk?
+        if (2ull * idx->n_prg <= (1ull << (31 - SORT_CH_BITS)) && !(prm->flags & PMAP_FLAG_SORT_WIDE))
+            KLAUNCH(sort_rank_kernel<true>, dim3(res->hit_cap / 256), SORT_ARGS);
+        else
+            KLAUNCH(sort_rank_kernel<false>, dim3(res->hit_cap / 256), SORT_ARGS);
+#undef SORT_ARGS
         kt.end(KT_SORT);
         HIP_TRY(hipGetLastError());
     }

@@ -267,8 +267,15 @@ __device__ __forceinline__ uint32_t clamp_count(const unsigned long long *p, uin
 // sort: hits arrive ordered by (read, position, prg, path rank).  A stable sort of each read's
 // segment by key = prg << 1 | !forward yields MinimizerHit::operator< order.  Each hit counts the
 // hits of its read that must precede it (rank by counting) and is written to that place.
-static const int SORT_CH = 2048;
+//
+// The keys of the block's reads are staged through LDS in chunks of SORT_CH.  NARROW (keys below
+// 2^(31 - SORT_CH_BITS), i.e. every index of up to half a million loci): a staged key carries its
+// place in the chunk below it, key << (SORT_CH_BITS + 1) | place, and "precedes hit i" is one
+// comparison with the hit's own (key, place) -- place 0 / all-ones for chunks after / before the
+// one that holds the hit, which counts smaller keys only / smaller and equal ones.
+static const int SORT_CH_BITS = 11, SORT_CH = 1 << SORT_CH_BITS;
 
+template <bool NARROW>
 __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long *__restrict__ n_hits_p,
                                                         uint32_t hit_cap, const uint32_t *__restrict__ h_read,
                                                         const uint32_t *__restrict__ h_key,
@@ -296,17 +303,25 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
     if (active && (threadIdx.x == 255 || i == n_hits - 1)) range[1] = e;
     __syncthreads();
     const uint32_t smin = range[0], emax = range[1];
+    const uint32_t PLACE = (2u << SORT_CH_BITS) - 1;      // SORT_CH_BITS + 1 bits: all-ones is above every place
     uint32_t c = 0;
     for (uint32_t base = smin; base < emax; base += SORT_CH) {
         const uint32_t n = min((uint32_t) SORT_CH, emax - base);
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < n; t += 256) keys[t] = h_key[base + t];
+        for (uint32_t t = threadIdx.x; t < n; t += 256)
+            keys[t] = NARROW ? (h_key[base + t] << (SORT_CH_BITS + 1) | t) : h_key[base + t];
         __syncthreads();
         if (active) {
             const uint32_t a = max(s, base), b = min(e, base + n);
-            const uint32_t mid = min(max(i, a), b);   // [a, mid) precede hit i, [mid', b) follow it
-            for (uint32_t j = a; j < mid; ++j) c += keys[j - base] <= key;
-            for (uint32_t j = max(a, i + 1); j < b; ++j) c += keys[j - base] < key;
+            if (NARROW) {
+                const uint32_t place = i < base ? 0u : i - base < n ? i - base : PLACE;
+                const uint32_t mine = key << (SORT_CH_BITS + 1) | place;
+                for (uint32_t j = a; j < b; ++j) c += keys[j - base] < mine;
+            } else {
+                const uint32_t mid = min(max(i, a), b);   // [a, mid) precede hit i, [mid', b) follow it
+                for (uint32_t j = a; j < mid; ++j) c += keys[j - base] <= key;
+                for (uint32_t j = max(a, i + 1); j < b; ++j) c += keys[j - base] < key;
+            }
         }
     }
     if (active) {
