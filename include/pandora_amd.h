@@ -10,7 +10,9 @@
  * Conventions: every function returns 0 on success and a non-zero PMAP_E* code
  * on failure; pmap_last_error() then returns a message (thread local).  All
  * pointers in the signatures are HOST pointers unless the name says `dev`.
- * Calls are blocking.  One process drives one GPU (select it with pmap_init).
+ * Calls are blocking.  One process drives one GPU (select it with pmap_init),
+ * from one thread at a time: the library keeps its streams and launch state in
+ * process-wide variables and takes no locks.
  */
 #ifndef PANDORA_AMD_H
 #define PANDORA_AMD_H

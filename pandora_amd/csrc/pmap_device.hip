@@ -490,7 +490,11 @@ static int run_pipeline(pmap_result *res) {
     aux.n_state_words = (uint32_t) (state_bytes / 8);
     aux.hbounds = res->hbounds.as<uint32_t>();
     aux.n_hb = 2 * (rd->n_reads + 1);
-    g_kt = &kt;
+    // the timer is registered for the launches of this call only, whichever way the function is left
+    struct TimerScope {
+        explicit TimerScope(KTimer *t) { g_kt = t; }
+        ~TimerScope() { g_kt = nullptr; }
+    } timer_scope(&kt);
 
     // ---- sketch (+ probe when fused)
     if (n_tiles) {
@@ -597,7 +601,6 @@ static int run_pipeline(pmap_result *res) {
         kt.end(KT_CLUSTER_KEEP);
         HIP_TRY(hipGetLastError());
     }
-    g_kt = nullptr;
     res->kt_recorded = kt.recorded;
     HIP_TRY(hipMemcpyAsync(res->hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, g_tail));
     HIP_TRY(hipEventRecord(res->done, g_tail));
