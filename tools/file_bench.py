@@ -20,10 +20,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--copies", type=int, default=3)
+    ap.add_argument("--copies", type=int, default=10)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--no-hits", action="store_true")
-    ap.add_argument("--batch-mbases", type=int, default=256)
+    ap.add_argument("--batch-mbases", type=int, default=0, help="0 = the library's default")
     args = ap.parse_args()
     import pandora_amd
     from pandora_amd import api, synth
