@@ -132,8 +132,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=3,
-                    help="steps in flight (1 = blocking pmap_map); with 3 the sketch stream never runs dry while the "
-                         "host waits for a result, and the tail kernels of one step run under the sketch kernel of the next")
+                    help="steps in flight (1 = blocking pmap_map); with 3 both sketch streams always hold a kernel "
+                         "while the host waits for a result, and the tail kernels of a step run next to the sketch "
+                         "kernels of the following ones")
     ap.add_argument("--last-stage", type=int, default=0,
                     help="stop the path after this stage (1 sketch, 2 hits, 3 sort, 4 clusters = all; 0 = all): for "
                          "experiments, the reported value is then not the metric")
