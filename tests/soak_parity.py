@@ -1,7 +1,9 @@
 """Parity soak on a GPU: many random small worlds (mostly the default w = 14, k <= 15) through every sketch
 kernel and sort variant, each compared with the oracle at every stage (tests/parity.py).
 
-    python tools/soak_parity.py [first seed] [cases]
+    python tests/soak_parity.py [first seed] [cases]
+
+(not collected by pytest: a longer run than the suite's random tests, started by hand)
 """
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
