@@ -135,7 +135,9 @@ static SketchKind sketch_kind(uint32_t w, uint32_t k, uint32_t flags, uint32_t *
     SketchKind kind = g_sketch_pref;
     if (flags & PMAP_FLAG_SKETCH_LDS) kind = SKETCH_LDS;
     else if (flags & PMAP_FLAG_SKETCH_NP8) kind = SKETCH_DPP8;
-    if (k > 15 || w != 14) kind = SKETCH_LDS;
+    // the register-window kernel serves k <= 15 with 2 <= w <= 16 (8 positions per lane: the default w only)
+    if (k > 15 || w < 2 || w > (uint32_t) DPP_MAX_W) kind = SKETCH_LDS;
+    else if (kind == SKETCH_DPP8 && w != 14) kind = SKETCH_DPP16;
     if (kind == SKETCH_DPP16) {
         *out_pos = DppTile<16>::OUT;
         *stride = DppTile<16>::POS;
@@ -512,7 +514,7 @@ static int run_pipeline(pmap_result *res) {
         else if (w == 1) SKETCH_LAUNCH(HT, FUSED, 1);                                                                 \
         else SKETCH_LAUNCH(HT, FUSED, 0);                                                                             \
     } while (0)
-        // k <= 15 with the default w: windows in registers (sketch_dpp_kernel), k = 15 at compile time
+        // k <= 15 with w <= 16: windows in registers (sketch_dpp_kernel); the default w = 14, k = 15 at compile time
 #define SKETCH_DPP(FUSED, WC, KC, NP)                                                                                 \
     KLAUNCH(HIP_KERNEL_NAME(sketch_dpp_kernel<FUSED, WC, KC, NP>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
 #define SKETCH_DPP_NP(NP)                                                                                             \
@@ -522,16 +524,30 @@ static int run_pipeline(pmap_result *res) {
         else if (k == 15) SKETCH_DPP(false, 14, 15, NP);                                                              \
         else SKETCH_DPP(false, 14, 0, NP);                                                                            \
     } while (0)
+        // any other w of 2..16: w at compile time, k from the argument
+#define SKETCH_DPP_W(WC)                                                                                              \
+    case WC:                                                                                                          \
+        if (fused) SKETCH_DPP(true, WC, 0, 16);                                                                       \
+        else SKETCH_DPP(false, WC, 0, 16);                                                                            \
+        break;
         uint32_t out_pos_, stride_;
         const SketchKind kind = sketch_kind(w, k, prm->flags, &out_pos_, &stride_);
-        if (kind == SKETCH_DPP16) {
+        if (kind == SKETCH_DPP16 && w == 14) {
             SKETCH_DPP_NP(16);
+        } else if (kind == SKETCH_DPP16) {
+            switch (w) {
+                SKETCH_DPP_W(2) SKETCH_DPP_W(3) SKETCH_DPP_W(4) SKETCH_DPP_W(5) SKETCH_DPP_W(6) SKETCH_DPP_W(7)
+                SKETCH_DPP_W(8) SKETCH_DPP_W(9) SKETCH_DPP_W(10) SKETCH_DPP_W(11) SKETCH_DPP_W(12) SKETCH_DPP_W(13)
+                SKETCH_DPP_W(15) SKETCH_DPP_W(16)
+                default: return pmap_fail(PMAP_EINVAL, "no register-window sketch kernel for this w");
+            }
         } else if (kind == SKETCH_DPP8) {
             SKETCH_DPP_NP(8);
         } else if (k32 && fused) SKETCH_DISPATCH(uint32_t, true);
         else if (k32) SKETCH_DISPATCH(uint32_t, false);
         else if (fused) SKETCH_DISPATCH(uint64_t, true);
         else SKETCH_DISPATCH(uint64_t, false);
+#undef SKETCH_DPP_W
 #undef SKETCH_DPP_NP
 #undef SKETCH_DPP
 #undef SKETCH_DISPATCH

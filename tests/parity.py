@@ -58,7 +58,10 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
     assert orc["n_dup_hits"] == 0
 
     # the default sketch kernel and, where (w, k) has more than one, the others
-    for sketch in ((None, "np8", "lds") if (w == 14 and k <= 15) else (None,)):
+    variants = (None,)
+    if k <= 15 and 2 <= w <= 16:
+        variants = (None, "np8", "lds") if w == 14 else (None, "lds")
+    for sketch in variants:
         # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
         res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, unfused=True,
                             sketch=sketch)

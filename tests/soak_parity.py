@@ -1,7 +1,7 @@
 """Parity soak on a GPU: many random small worlds (mostly the default w = 14, k <= 15) through every sketch
 kernel and sort variant, each compared with the oracle at every stage (tests/parity.py).
 
-    python tests/soak_parity.py [first seed] [cases]
+    python tests/soak_parity.py [first seed] [cases] [w_max: w uniform in 1..w_max instead of mostly 14]
 
 (not collected by pytest: a longer run than the suite's random tests, started by hand)
 """
@@ -21,6 +21,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     rng = np.random.default_rng(seed0 + case)
     k = int(rng.choice([15, 15, 15, 14, 12, 9, 6]))
     w = 14 if rng.random() < 0.8 else int(rng.integers(1, 40))
+    if len(sys.argv) > 3:
+        w = int(rng.integers(1, int(sys.argv[3]) + 1))
     loci = [synth.random_dna(int(rng.integers(200, 6000)), rng) for _ in range(int(rng.integers(1, 8)))]
     if rng.random() < 0.5:
         loci.append(loci[0].copy())
