@@ -155,7 +155,7 @@ typedef struct {
  * PMAP_STAGE_SKETCH implies it. */
 #define PMAP_FLAG_UNFUSED 1u
 /* Diagnostic choice of the sketch kernel where more than one gives the same results.  k <= 15 with
- * 2 <= w <= 16 runs by default on the kernel with 16 positions per lane and the windows in
+ * w <= 16 runs by default on the kernel with 16 positions per lane and the windows in
  * registers; PMAP_FLAG_SKETCH_LDS takes the general kernel (windows through LDS) that serves every
  * other (w, k), PMAP_FLAG_SKETCH_NP8 (w = 14 only) the register kernel with 8 positions per lane.
  * The environment variable PMAP_SKETCH=np8|lds, read by pmap_init, sets the default. */

@@ -135,8 +135,8 @@ static SketchKind sketch_kind(uint32_t w, uint32_t k, uint32_t flags, uint32_t *
     SketchKind kind = g_sketch_pref;
     if (flags & PMAP_FLAG_SKETCH_LDS) kind = SKETCH_LDS;
     else if (flags & PMAP_FLAG_SKETCH_NP8) kind = SKETCH_DPP8;
-    // the register-window kernel serves k <= 15 with 2 <= w <= 16 (8 positions per lane: the default w only)
-    if (k > 15 || w < 2 || w > (uint32_t) DPP_MAX_W) kind = SKETCH_LDS;
+    // the register-window kernel serves k <= 15 with w <= 16 (8 positions per lane: the default w only)
+    if (k > 15 || w < 1 || w > (uint32_t) DPP_MAX_W) kind = SKETCH_LDS;
     else if (kind == SKETCH_DPP8 && w != 14) kind = SKETCH_DPP16;
     if (kind == SKETCH_DPP16) {
         *out_pos = DppTile<16>::OUT;
@@ -524,7 +524,7 @@ static int run_pipeline(pmap_result *res) {
         else if (k == 15) SKETCH_DPP(false, 14, 15, NP);                                                              \
         else SKETCH_DPP(false, 14, 0, NP);                                                                            \
     } while (0)
-        // any other w of 2..16: w at compile time, k from the argument
+        // any other w of 1..16: w at compile time, k from the argument
 #define SKETCH_DPP_W(WC)                                                                                              \
     case WC:                                                                                                          \
         if (fused) SKETCH_DPP(true, WC, 0, 16);                                                                       \
@@ -536,7 +536,7 @@ static int run_pipeline(pmap_result *res) {
             SKETCH_DPP_NP(16);
         } else if (kind == SKETCH_DPP16) {
             switch (w) {
-                SKETCH_DPP_W(2) SKETCH_DPP_W(3) SKETCH_DPP_W(4) SKETCH_DPP_W(5) SKETCH_DPP_W(6) SKETCH_DPP_W(7)
+                SKETCH_DPP_W(1) SKETCH_DPP_W(2) SKETCH_DPP_W(3) SKETCH_DPP_W(4) SKETCH_DPP_W(5) SKETCH_DPP_W(6) SKETCH_DPP_W(7)
                 SKETCH_DPP_W(8) SKETCH_DPP_W(9) SKETCH_DPP_W(10) SKETCH_DPP_W(11) SKETCH_DPP_W(12) SKETCH_DPP_W(13)
                 SKETCH_DPP_W(15) SKETCH_DPP_W(16)
                 default: return pmap_fail(PMAP_EINVAL, "no register-window sketch kernel for this w");

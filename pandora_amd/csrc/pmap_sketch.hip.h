@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     uint32_t w_arg, uint32_t k_arg, const PmapSlot *__restrict__ slots, uint32_t log2cap,
     const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
     uint4 *__restrict__ tile_cnt, SketchAux aux) {
-    static_assert(WC >= 2 && WC <= DPP_MAX_W && WC - 1 <= DPP_HALO, "window steps must stay within the neighbouring lane");
+    static_assert(WC >= 1 && WC <= DPP_MAX_W && WC - 1 <= DPP_HALO, "window steps must stay within the neighbouring lane");
     static_assert(NP == 8 || NP == 16, "a lane starts at a word or half-word boundary");
     typedef DppTile<NP> T;
     (void) w_arg;

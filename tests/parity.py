@@ -59,7 +59,7 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
 
     # the default sketch kernel and, where (w, k) has more than one, the others
     variants = (None,)
-    if k <= 15 and 2 <= w <= 16:
+    if k <= 15 and 1 <= w <= 16:
         variants = (None, "np8", "lds") if w == 14 else (None, "lds")
     for sketch in variants:
         # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
