@@ -3,6 +3,7 @@
 // (src/minihits.cpp:95-109, src/utils.cpp:251-288), the add_node sequence
 // (src/utils.cpp:338-352, src/pangenome/pangraph.cpp:43-140) and the read loop of
 // pangraph_from_read_file (src/utils.cpp:379-455).
+#include <sys/mman.h>
 #include <zlib.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -220,6 +221,39 @@ struct PgHit {
     uint8_t fwd;
 };
 
+// Growing array of hits: realloc moves big blocks by remapping their pages instead of copying them
+// (a std::vector of several hundred MB copies itself at every growth step), and the block asks for
+// huge pages so that filling it does not take a page fault per 4 KiB.
+struct HitBuf {
+    PgHit *p = nullptr;
+    size_t n = 0, cap = 0;
+    HitBuf() = default;
+    HitBuf(const HitBuf &) = delete;
+    HitBuf &operator=(const HitBuf &) = delete;
+    ~HitBuf() { free(p); }
+    size_t size() const { return n; }
+    PgHit *begin() { return p; }
+    PgHit *end() { return p + n; }
+    const PgHit &operator[](size_t i) const { return p[i]; }
+    bool reserve_more(size_t extra) {
+        if (n + extra <= cap) return true;
+        size_t ncap = std::max<size_t>(n + extra, cap + cap / 2 + 4096);
+        PgHit *q = (PgHit *) realloc(p, ncap * sizeof(PgHit));
+        if (!q) return false;
+        p = q;
+        cap = ncap;
+#ifdef MADV_HUGEPAGE
+        if (ncap * sizeof(PgHit) >= (size_t) 4 << 20) {
+            const uintptr_t a = ((uintptr_t) p + 4095) & ~(uintptr_t) 4095;
+            const uintptr_t e = ((uintptr_t) p + ncap * sizeof(PgHit)) & ~(uintptr_t) 4095;
+            if (e > a) (void) madvise((void *) a, e - a, MADV_HUGEPAGE);
+        }
+#endif
+        return true;
+    }
+    void push_unchecked(const PgHit &h) { p[n++] = h; }
+};
+
 struct PgRead {
     std::vector<uint32_t> nodes;
     std::vector<uint8_t> orient;
@@ -228,7 +262,7 @@ struct PgRead {
 struct pmap_pangraph {
     std::map<uint32_t, uint32_t> node_covg;   // node id (= prg id) -> covg
     std::map<uint32_t, PgRead> reads;
-    std::vector<PgHit> hits;
+    HitBuf hits;
     std::vector<uint32_t> call_prg, call_read, call_size;
     std::vector<uint8_t> call_fwd;
     bool hits_sorted = false;
@@ -456,9 +490,11 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, pmap_pangraph *pg,
         if (!alive[j]) continue;
         const uint64_t c = order[j];
         pg_add_node(pg, prg[c], rid[c], size[c], fwd[c] != 0);
-        if (keep_hits)
+        if (keep_hits) {
+            if (!pg->hits.reserve_more(size[c])) return pmap_fail(PMAP_ELIMIT, "out of host memory for the hits of the reads");
             for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
-                pg->hits.push_back(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
+                pg->hits.push_unchecked(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
+        }
     }
     pg->hits_sorted = false;
     if (cov) {
