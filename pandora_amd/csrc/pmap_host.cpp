@@ -10,7 +10,9 @@
 #endif
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -342,9 +344,15 @@ struct BatchQueue {
     std::deque<Batch *> ready, free_list;
     bool done = false;      // the reader has pushed its last batch
     bool abort = false;     // the consumer gave up: the reader must stop
+    double reader_waited = 0, mapper_waited = 0;    // seconds each side spent waiting for the other (PMAP_TRACE_PIPELINE)
+    static double now() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
     Batch *get_free() {
         std::unique_lock<std::mutex> l(m);
+        const double t0 = now();
         cv.wait(l, [&] { return abort || !free_list.empty(); });
+        reader_waited += now() - t0;
         if (abort) return nullptr;
         Batch *b = free_list.front();
         free_list.pop_front();
@@ -360,7 +368,9 @@ struct BatchQueue {
     }
     Batch *get_ready() {    // nullptr: no more batches
         std::unique_lock<std::mutex> l(m);
+        const double t0 = now();
         cv.wait(l, [&] { return done || !ready.empty(); });
+        mapper_waited += now() - t0;
         if (ready.empty()) return nullptr;
         Batch *b = ready.front();
         ready.pop_front();
@@ -575,6 +585,9 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     if (rc == PMAP_OK && pending >= 0) rc = finish_batch(idx, ress[pending], pg, keep_hits, pg->cov);
     q.stop();
     reader.join();
+    if (getenv("PMAP_TRACE_PIPELINE"))
+        fprintf(stderr, "[pmap] read-file pipeline: the mapping thread waited %.3f s for batches, the reader %.3f s for free buffers\n",
+                q.mapper_waited, q.reader_waited);
     if (rc == PMAP_OK && rr.rc) rc = pmap_fail(rr.rc, rr.error);
     for (int i = 0; i < 2; ++i) {
         pmap_result_destroy(ress[i]);
