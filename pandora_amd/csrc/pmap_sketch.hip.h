@@ -642,8 +642,11 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     const int64_t P0 = (int64_t) g * T::OUT - DPP_HALO;        // position 0 of the tile, a multiple of 16
     const int32_t wbase = (int32_t) (P0 >> 4);                  // -1 for g = 0
     const uint32_t P0lo = (uint32_t) P0;
-    for (int t = lane; t < T::NWD; t += 64) {
-        const int32_t wi = wbase + t;
+    // the tile's POS / 16 packed words with their read's start / length / index, one per lane, and the word
+    // behind them (the k-mers of the last positions reach into it) by one more lane
+    const int NW = T::POS / 16;
+    if (lane < NW) {
+        const int32_t wi = wbase + lane;
         uint32_t word = 0, ms = 0, ml = 0, ri = 0;
         if (wi >= 0 && wi < (int32_t) n_words) {
             const uint2 wd = words[wi];
@@ -654,10 +657,14 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             ml = rm.y;
             if (ml + 1 < w + k) ml = 0;             // too short to sketch (src/seq.cpp:92-94)
         }
-        W[t] = word;
-        mstart[t] = ms;
-        mlen[t] = ml;
-        wr[t] = ri;
+        W[lane] = word;
+        mstart[lane] = ms;
+        mlen[lane] = ml;
+        wr[lane] = ri;
+    }
+    if (lane == (NW < 64 ? NW : 0)) {
+        const int32_t wi = wbase + NW;
+        W[NW] = wi >= 0 && wi < (int32_t) n_words ? words[wi].x : 0u;
     }
     wave_lds_sync();
 
