@@ -181,8 +181,8 @@ __device__ __forceinline__ uint32_t revcomp16(uint32_t v) {
     return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
 }
 
-// sum over the wavefront, valid in every lane
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+// inclusive prefix sum over the lanes of the wavefront
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     // inclusive scan inside each row of 16 lanes, then row totals carried across rows
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);   // row_shr:1
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);   // row_shr:2
@@ -190,7 +190,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);   // row_shr:8
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
-    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+    return v;
+}
+
+// sum over the wavefront, valid in every lane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    return (uint32_t) __builtin_amdgcn_readlane((int) wave_incl_scan(v), 63);
 }
 
 // Minimum over the a+1 positions ending at each of the 4 positions of quad Q (backward window),
@@ -738,16 +743,14 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
 
     // ---- compaction in position order with ballots: list[e] = index of the e-th minimizer in the tile
     const bool inr = (uint32_t) (lane - DPP_HALO / NP) < (uint32_t) (T::OUT / NP);
-    const unsigned long long INR_LANES = (~0ull >> (64 - T::OUT / NP)) << (DPP_HALO / NP);
-    uint32_t o = 0, n = 0;
+    // every lane counts its own flags (one add-with-carry per position), a prefix sum over the lanes
+    // places the lane's first minimizer
+    uint32_t mine = 0;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        // (the ballot of a bare comparison is the comparison's own result; the halo lanes go away in scalar code)
-        const unsigned long long b = ballot64(L[j] == cmp[j]) & INR_LANES;
-        // flags of lower lanes are earlier positions whatever their j
-        o += __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0));
-        n += __popcll(b);
-    }
+    for (int j = 0; j < NP; ++j) mine += (inr && L[j] == cmp[j]) ? 1u : 0u;
+    const uint32_t upto = wave_incl_scan(mine);
+    const uint32_t n = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
+    uint32_t o = upto - mine;
     const uint32_t laneNP = (uint32_t) NP * (uint32_t) lane;
     asm volatile("" : "+v"(o));         // keeps the sum whole: one scaling to a byte offset, not one per term
     uint16_t *lp = list + o;
