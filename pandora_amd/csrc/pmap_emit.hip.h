@@ -2,7 +2,7 @@
 // Included by pmap_kernels.hip.h only.
 //
 // The sketch kernel leaves, per wavefront tile g, tile_cnt[g] = {minimizers, entries, hits, 0} and
-// the entries themselves in the tile's 512 slots of `ents`, 32 bytes each:
+// the entries themselves in the tile's slots of `ents` (slot stride = positions of a tile), 32 bytes each:
 // {read index, position | strand << 31, first record's index, record count} {the first record}.
 #ifndef PMAP_EMIT_HIP_H
 #define PMAP_EMIT_HIP_H
