@@ -25,8 +25,13 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 # The library keeps four streams busy (two for sketch kernels, one for everything after them, one for
 # uploads); torch and the collective library bring their own.  With the HIP default of 4 hardware queues
 # per process the two sketch streams then end up on one queue and stop overlapping (measured: 433 instead
-# of 463 Gbases/s once the process group exists).  Read by the HIP runtime when it starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# of 463 Gbases/s once the process group exists).  Read by the HIP runtime when it starts; the GPU boxes of
+# this pool export 4, so a default would not be enough: anything below 8 is raised.
+try:
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+except ValueError:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 # kernels of each phase (names of pmap_kernel_name)
 PHASES = {
