@@ -698,6 +698,10 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     const uint32_t ylo = revcomp16(x0), yhi = revcomp16(x1);
     uint32_t own[NP];
     uint32_t nstrand = 0;           // bit NP-1 - j: h_fwd > h_rc at position j, i.e. strand = 0
+    // Sparse sketches in fused mode: only the few minimizers that have records need their strand, and
+    // hashing their forward k-mer once more (strand = the canonical hash is the forward one) costs less
+    // than keeping two instructions per position here.
+    constexpr bool LAZY_STRAND = FUSED && WC >= 8;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         uint32_t fwd;
@@ -714,13 +718,13 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
         const uint32_t rc = j ? __builtin_amdgcn_alignbit(yhi, ylo, 2 * j) : ylo;
         const uint32_t hf = hash64_u32(fwd, mask, hw), hr = hash64_u32(rc, mask, hw);
         // hashes are below 2^30: the sign of hr - hf tells hf > hr; strand = (hf <= hr)
-        nstrand = __builtin_amdgcn_alignbit(nstrand, hr - hf, 31);   // nstrand << 1 | sign
+        if constexpr (!LAZY_STRAND) nstrand = __builtin_amdgcn_alignbit(nstrand, hr - hf, 31);   // nstrand << 1 | sign
         own[j] = tmin(hf, hr);
     }
 #pragma unroll
     for (int q = 0; q < NP / 4; ++q)
         *(uint4 *) (h + NP * lane + 4 * q) = make_uint4(own[4 * q], own[4 * q + 1], own[4 * q + 2], own[4 * q + 3]);
-    strands[lane] = ~nstrand;
+    if constexpr (!LAZY_STRAND) strands[lane] = ~nstrand;
 
     // ---- L[t] = minimum of the full window ending at k-mer t, 0 if that window is not inside one read;
     //      k-mer i is a minimizer iff it equals the largest of the minima of the windows containing it.
@@ -819,9 +823,17 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             uint32_t cnt = 0, off = 0, ps = 0, rd = 0;
             uint4 first = make_uint4(0, 0, 0, 0);
             if (e < n2) {
-                const uint32_t i = list[e], wj = i >> 4;
-                index_lookup(slots, log2cap, nullptr, 0u, (uint64_t) h[i], &cnt, &off, &first);
-                const uint32_t st = strands[i / NP] << (32 - NP + (i & (NP - 1)));
+                const uint32_t i = list[e], wj = i >> 4, hv = h[i];
+                index_lookup(slots, log2cap, nullptr, 0u, (uint64_t) hv, &cnt, &off, &first);
+                uint32_t st;
+                if constexpr (LAZY_STRAND) {
+                    // the forward k-mer at position i: 2 (i & 15) bits into the words wj, wj + 1
+                    const uint64_t xx = ((uint64_t) W[wj] << 32) | W[wj + 1];
+                    const uint32_t top = (uint32_t) ((xx << (2u * (i & 15u))) >> 32);
+                    st = hash64_u32(top >> (32 - 2 * k), mask, hw) == hv ? 0x80000000u : 0u;   // h_fwd <= h_rc
+                } else {
+                    st = strands[i / NP] << (32 - NP + (i & (NP - 1)));
+                }
                 ps = (P0lo + i - mstart[wj]) | (st & 0x80000000u);     // position inside the read, strand on top
                 rd = wr[wj];
             }
