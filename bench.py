@@ -181,13 +181,21 @@ def main():
     pandora_amd.init(device)
 
     # same index on every rank (replicated), a different shard of reads per rank
+    def progress(msg):     # a big workload takes minutes to synthesise: say so on stderr
+        if rank == 0:
+            print("[bench] %s (%.0f s)" % (msg, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    progress("synthesising workload %s" % args.workload)
     si, bases, offsets, prm = synth.workload(args.workload, seed=1, scale=args.scale, shard=rank)
+    progress("flattening the index: %d keys, %d records" % (len(si.keys), len(si.rec_prg)))
     fraction = api.fraction(prm["e_rate"], prm["k"])
     expected = 0xFFFFFFFF
     if prm["illumina"]:
         expected = 150 * 2 // prm["w"]
     gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
                             si.iv_start, si.iv_len, si.min_path_length)
+    progress("index on the device, uploading %d bases" % len(bases))
     t0 = time.perf_counter()
     reads = api.Reads(bases, offsets)
     upload_s = time.perf_counter() - t0

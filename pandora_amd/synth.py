@@ -225,6 +225,7 @@ def workload(name, seed=1, scale=1.0, shard=0):
     illumina_w1   the same with w=1 (dense minimizers; the reference's threshold rejects every cluster)
     nanopore_20k  20 000 loci, 15 000 nanopore reads (30x of the genome), w=14 k=15
     illumina_20k_w1  20 000 loci, 400 000 reads of 150 bp, w=1 k=15
+    nanopore_200k 200 000 loci (27 M keys, multi-GB table), 15 000 nanopore reads, w=14 k=15
 
     `shard` selects an independent batch of reads over the same index and genome (one per GPU rank).
     """
@@ -244,10 +245,11 @@ def workload(name, seed=1, scale=1.0, shard=0):
         genome = make_genome(loci, np.random.default_rng(seed + 1))
         bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 3, shard]), fixed_len=150, e_rate=0.001)
         prm = dict(w=w, k=k, max_diff=2 * k + 1, e_rate=0.001, min_cluster_size=10, illumina=True)
-    elif name in ("nanopore_20k", "illumina_20k_w1"):
-        # E. coli-scale index: 20 000 loci, a 64 MB slot table (beyond every cache but the Infinity Cache)
+    elif name in ("nanopore_20k", "illumina_20k_w1", "nanopore_200k"):
+        # E. coli-scale index: 20 000 loci, a 128 MB slot table (beyond every cache but the Infinity Cache);
+        # multi-species scale: 200 000 loci, a 2 GB slot table in HBM
         ill = name == "illumina_20k_w1"
-        w, k, n_loci = (1 if ill else 14), 15, 20000
+        w, k, n_loci = (1 if ill else 14), 15, (200000 if name == "nanopore_200k" else 20000)
         loci = make_loci(n_loci, rng)
         idx = build_index(loci, w, k)
         genome = make_genome(loci, np.random.default_rng(seed + 1))
