@@ -98,3 +98,27 @@ def test_slices_against_oracle(world, first, count):
     np.testing.assert_array_equal(h["pos"][sel], orc["hit_pos"])
     np.testing.assert_array_equal(h["rec"][sel], orc["hit_rec"])
     np.testing.assert_array_equal(h["prg"][sel], orc["hit_prg"])
+
+
+def test_big_index_slice_against_oracle(gpu):
+    """20 000 loci: 2.8 M keys, a 128 MB table beyond the L2 caches and a presence filter with two bits per
+    key.  A slice of the nanopore reads and a slice of 150-bp reads (w = 1: every k-mer is looked up) against
+    the oracle on the same index."""
+    si, bases, off, prm = synth.workload("nanopore_20k", seed=1, scale=0.02)
+    gidx = gpu_index(si)
+    info = gidx.info()
+    assert info["n_keys"] > 2_000_000 and info["filter_bits_per_key"] == 2
+    n = min(120, len(off) - 1)
+    sub_off = off[:n + 1]
+    cn, _ = compare_batch(si, bases[:int(sub_off[-1])], sub_off, prm["w"], prm["k"], prm["max_diff"],
+                          api.fraction(prm["e_rate"], prm["k"]), prm["min_cluster_size"], gidx=gidx)
+    assert cn["n_hits"] > 10000
+    # short reads cut from the same ones, every k-mer a minimizer
+    rng = np.random.default_rng(3)
+    starts = rng.integers(0, int(sub_off[-1]) - 150, 3000)
+    short = np.concatenate([bases[int(s):int(s) + 150] for s in starts])
+    soff = np.arange(0, 150 * len(starts) + 1, 150, dtype=np.uint64)
+    cn, _ = compare_batch(si, short, soff, 1, prm["k"], 31, api.fraction(0.001, prm["k"]), 10, expected_kmers=300,
+                          gidx=gidx)
+    assert cn["n_minimizers"] > 300000
+    gidx.close()
