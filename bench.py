@@ -129,9 +129,9 @@ def cpu_baseline(si, bases, offsets, prm, fraction, budget_s=10.0, threads_budge
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200,
+    ap.add_argument("--steps", type=int, default=1000,
                     help="timed steps (a step takes a quarter of a millisecond: a few hundred of them make the "
-                         "barrier and synchronisation at both ends of the timed region negligible)")
+                         "barrier, the pipeline fill and the synchronisation at both ends of the timed region negligible)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="nanopore_1k")
     ap.add_argument("--scale", type=float, default=1.0)
