@@ -199,7 +199,7 @@ struct pmap_result {
     DevBuf cstart, k_rows;
     DevBuf thr;
     std::vector<uint32_t> thr_host;
-    const pmap_index *thr_idx = nullptr;
+    uint64_t thr_serial = 0;          // pmap_index::serial the table was built from (0 = none yet)
     float thr_fraction = 0;
     uint32_t thr_min = 0, thr_exp = 0;
     hipEvent_t kev[2 * PMAP_N_KERNELS];
@@ -453,7 +453,11 @@ static int device_scan(pmap_result *res, const uint32_t *in, uint32_t *out, uint
     return PMAP_OK;
 }
 
-static uint32_t round_up(uint64_t v, uint32_t m) { return (uint32_t) ((v + m - 1) / m * m); }
+// v rounded up to a multiple of m, clamped to the largest multiple of m that fits 32 bits
+static uint32_t round_up(uint64_t v, uint32_t m) {
+    const uint64_t r = (v + m - 1) / m * m, top = 0xFFFFFFFFull / m * m;
+    return (uint32_t) (r < top ? r : top);
+}
 
 // enqueues the whole pipeline once with the current capacities; the counters arrive in res->hc
 // when res->done has happened
@@ -692,7 +696,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
 
     // per-prg size threshold (src/utils.cpp:211-213, 219-220), refreshed when its inputs change
     if (last >= PMAP_STAGE_CLUSTER &&
-        (res->thr_idx != idx || res->thr_fraction != prm->fraction || res->thr_min != prm->min_cluster_size ||
+        (res->thr_serial != idx->serial || res->thr_fraction != prm->fraction || res->thr_min != prm->min_cluster_size ||
          res->thr_exp != prm->expected_kmers)) {
         res->thr_host.assign(idx->n_prg + 1, 0);
         for (uint32_t p = 0; p < idx->n_prg; ++p)
@@ -702,7 +706,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
         HIP_TRY(hipMemcpyAsync(res->thr.p, res->thr_host.data(), sizeof(uint32_t) * res->thr_host.size(),
                                hipMemcpyHostToDevice, g_tail));
         HIP_TRY(hipStreamSynchronize(g_tail));   // thr_host is pageable and may change before the copy ran
-        res->thr_idx = idx;
+        res->thr_serial = idx->serial;
         res->thr_fraction = prm->fraction;
         res->thr_min = prm->min_cluster_size;
         res->thr_exp = prm->expected_kmers;
@@ -740,7 +744,9 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         if (n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
         bool again = false;
         if (last >= PMAP_STAGE_HITS && n_hits > res->hit_cap) {
-            if ((rc = ensure_hit_buffers(res, round_up(n_hits + n_hits / 8, CUT_BLOCK)))) return rc;
+            const uint32_t want = round_up(n_hits + n_hits / 8, CUT_BLOCK);
+            if (want < n_hits) return pmap_fail(PMAP_ELIMIT, "too many hits in one batch for 32-bit hit buffers");
+            if ((rc = ensure_hit_buffers(res, want))) return rc;
             again = true;
         }
         // at most one cluster per hit; when the hits overflowed the cluster count is only a lower bound

@@ -2,6 +2,7 @@
 #ifndef PMAP_INTERNAL_H
 #define PMAP_INTERNAL_H
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -53,7 +54,15 @@ PMAP_HD static inline uint32_t pmap_filter_mask(uint32_t hm, uint32_t fb) {
     return m;
 }
 
+// A number no other index object of this process ever gets: caches keyed on an index compare this, not
+// the object's address (the allocator hands the address of a destroyed index to the next one).
+inline uint64_t pmap_new_serial() {
+    static std::atomic<uint64_t> next{0};
+    return ++next;
+}
+
 struct pmap_index {
+    const uint64_t serial = pmap_new_serial();
     uint32_t k = 0;
     uint32_t n_prg = 0;
     uint64_t n_keys = 0, n_recs = 0, n_paths = 0;
