@@ -188,6 +188,20 @@ int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *reads, const pma
                    pmap_result_t **result);
 int pmap_map_wait(pmap_result_t *result);
 
+/* Device-side outputs of pmap_map_noalloc, allocated by the caller: hits in
+ * MinimizerHit::operator< order as five arrays of hit_cap entries each (read =
+ * index of the read in the batch, key = prg_id << 1 | !is_forward, position in
+ * the read, path rank, record index in the caller's numbering) and the clusters
+ * kept by define_clusters as rows of eight 32-bit words {first hit, size, read,
+ * key, first position, last position, path rank of the first hit, cluster
+ * number before the size threshold}.  All pointers are DEVICE pointers. */
+typedef struct {
+    uint32_t hit_cap;           /* at least 8192; used in multiples of 8192, at most 2^20 */
+    uint32_t *hit_read, *hit_key, *hit_pos, *hit_rank, *hit_rec;
+    uint32_t cluster_cap;       /* at least 1024; used in multiples of 1024, at most 2^20 */
+    uint32_t *cluster_rows;
+} pmap_dev_out_t;
+
 #define PMAP_N_TIMERS 8
 typedef struct {
     uint32_t n_reads;
@@ -202,6 +216,26 @@ typedef struct {
     float ms[PMAP_N_TIMERS];
 } pmap_counts_t;
 int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out);
+
+/* pmap_map for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops such as adaptive sampling on a running nanopore
+ * flow cell, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same kernels and results as pmap_map in its default mode, but no
+ * hipMalloc / hipFree / event creation inside the call: everything between the
+ * inputs and the outputs lives in a 64 MiB array that is part of the library's
+ * device image (one copy per GPU, held until the process ends), whose address
+ * pmap_init(device) looks up once per device.  Hence the limits, reported as
+ * PMAP_ELIMIT: a batch of at most 2^20 tile entry slots (about one million
+ * bases after every read is padded to a multiple of 16), 2^17 reads, 2^20 hits,
+ * 2^20 clusters before the size threshold, an index of at most 2^20 PRGs.
+ * Before the call: pmap_init on this device, pmap_index_upload_now(idx),
+ * pmap_reads_create / pmap_reads_update for the batch.  The call blocks until
+ * the outputs are complete; *counts receives the totals (also when the outputs
+ * were too small: PMAP_ELIMIT, and the counts say what would have fitted).
+ * Every call on one GPU uses that GPU's one array: calls that overlap on one
+ * GPU race; calls on different GPUs do not. */
+int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *reads, const pmap_params_t *prm,
+                     const pmap_dev_out_t *out, pmap_counts_t *counts);
 
 /* Per-kernel HIP-event times (milliseconds, on the library's stream) of the
  * last pmap_map call made with profile != 0 (the events ride on the kernel

@@ -43,6 +43,12 @@ class Counts(C.Structure):
                 ("ms", C.c_float * PMAP_N_TIMERS)]
 
 
+class DevOut(C.Structure):
+    _fields_ = [("hit_cap", C.c_uint32), ("hit_read", C.c_void_p), ("hit_key", C.c_void_p), ("hit_pos", C.c_void_p),
+                ("hit_rank", C.c_void_p), ("hit_rec", C.c_void_p), ("cluster_cap", C.c_uint32),
+                ("cluster_rows", C.c_void_p)]
+
+
 class MapArgs(C.Structure):
     _fields_ = [("w", C.c_uint32), ("k", C.c_uint32), ("max_diff", C.c_int32), ("e_rate", C.c_float),
                 ("min_cluster_size", C.c_uint32), ("genome_size", C.c_uint32), ("illumina", C.c_int),
@@ -79,6 +85,7 @@ SIGNATURES = {
     "pmap_map": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "pmap_map_async": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "pmap_map_wait": (C.c_int, [C.c_void_p]),
+    "pmap_map_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(DevOut), C.POINTER(Counts)]),
     "pmap_result_counts": (C.c_int, [C.c_void_p, C.POINTER(Counts)]),
     "pmap_result_kernel_ms": (C.c_int, [C.c_void_p, f32p]),
     "pmap_kernel_name": (C.c_char_p, [C.c_int]),

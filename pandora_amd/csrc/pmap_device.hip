@@ -57,6 +57,45 @@ static bool g_ready = false;
 enum SketchKind { SKETCH_LDS = 0, SKETCH_DPP8 = 8, SKETCH_DPP16 = 16 };
 static SketchKind g_sketch_pref = SKETCH_DPP16;
 
+// ---------------------------------------------------------------------------
+// Scratch memory of pmap_map_noalloc, the entry point that allocates nothing: everything pmap_map keeps
+// in buffers it allocates itself between its inputs and outputs (counters and the words of the chained
+// prefix sums, tile counters, tile entries, hits before the sort, per-read hit bounds, cluster starts,
+// per-prg thresholds) lives here instead.  Every GPU the library runs on holds its own copy of the
+// array, at its own address, until the process ends.  In host code the array's name is only a handle
+// for hipGetSymbolAddress: pmap_init asks for the address once per device and host code uses nothing but
+// that pointer (kernel arguments, copies).
+static const size_t NA_MAX_SLOTS = 1u << 20;       // tile slots (tiles x slot stride): about 1 Mbases of padded reads
+static const size_t NA_MAX_HITS = 1u << 20;
+static const size_t NA_MAX_CLUSTERS = 1u << 20;
+static const size_t NA_MAX_READS = 1u << 17;
+static const size_t NA_MAX_PRG = 1u << 20;
+static const size_t NA_MAX_TILES = NA_MAX_SLOTS / 512;   // the smallest slot stride of a tile is 512
+static const size_t NA_OFF_STATE = 0;                                                      // 256 KiB
+static const size_t NA_OFF_GROUP = NA_OFF_STATE + (256u << 10);                            // 64 KiB
+static const size_t NA_OFF_TILECNT = NA_OFF_GROUP + (64u << 10);                           // 16 B per tile
+static const size_t NA_OFF_HBOUNDS = NA_OFF_TILECNT + 16 * (NA_MAX_TILES + 16);            // 8 B per read
+static const size_t NA_OFF_THR = NA_OFF_HBOUNDS + 8 * (NA_MAX_READS + 32);                 // 4 B per prg
+static const size_t NA_OFF_CSTART = NA_OFF_THR + 4 * (NA_MAX_PRG + 64);                    // 4 B per cluster
+static const size_t NA_OFF_HITS = NA_OFF_CSTART + 4 * (NA_MAX_CLUSTERS + 64);              // 5 x 4 B per hit
+static const size_t NA_OFF_ENTS = NA_OFF_HITS + 5 * 4 * NA_MAX_HITS;                       // 32 B per tile slot
+static const size_t NA_SCRATCH_BYTES = NA_OFF_ENTS + 32 * NA_MAX_SLOTS;
+static_assert(NA_SCRATCH_BYTES <= (64u << 20), "the scratch array is documented as 64 MiB");
+static_assert(NA_OFF_GROUP % 256 == 0 && NA_OFF_TILECNT % 256 == 0 && NA_OFF_HBOUNDS % 256 == 0 &&
+              NA_OFF_THR % 256 == 0 && NA_OFF_CSTART % 256 == 0 && NA_OFF_HITS % 256 == 0 && NA_OFF_ENTS % 256 == 0,
+              "every part of the scratch array starts on a 256-byte boundary");
+static __device__ __align__(256) unsigned char pmap_scratch[64u << 20];
+
+struct pmap_result;
+static const int NA_MAX_DEVICES = 64;
+struct NoAllocDevice {
+    unsigned char *scratch = nullptr;     // this device's copy of pmap_scratch (hipGetSymbolAddress)
+    pmap_result *view = nullptr;          // a result whose buffers are views of the scratch array and of the caller's outputs
+    uint32_t *thr_stage = nullptr;        // pinned staging of the per-prg thresholds
+};
+static NoAllocDevice g_na[NA_MAX_DEVICES];
+static int noalloc_setup(int dev);
+
 extern "C" int pmap_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -72,6 +111,9 @@ extern "C" int pmap_init(int device) {
     }
     const char *sk = getenv("PMAP_SKETCH");
     g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    if (int rc = noalloc_setup(cur)) return rc;
     g_ready = true;
     return PMAP_OK;
 }
@@ -96,8 +138,10 @@ static int ensure_init() {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool owned = true;      // false: a view of memory that belongs to someone else (never grown, never freed)
     int ensure(size_t bytes) {
         if (bytes <= cap) return PMAP_OK;
+        if (!owned) return pmap_fail(PMAP_ELIMIT, "a fixed-size device buffer is too small for this batch");
         if (p) HIP_TRY(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -107,9 +151,14 @@ struct DevBuf {
         return PMAP_OK;
     }
     void release() {
-        if (p) (void) hipFree(p);
+        if (p && owned) (void) hipFree(p);
         p = nullptr;
         cap = 0;
+    }
+    void view(void *ptr, size_t bytes) {
+        p = ptr;
+        cap = bytes;
+        owned = false;
     }
     template <typename T>
     T *as() const { return (T *) p; }
@@ -220,6 +269,8 @@ struct pmap_result {
                 &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &cstart, &k_rows, &thr};
     }
 };
+
+static int new_result(pmap_result **out);
 
 // ---------------------------------------------------------------------------
 // index upload
@@ -660,15 +711,12 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     if (!idx->d_slots && (rc = pmap_index_upload(const_cast<pmap_index *>(idx)))) return rc;
     pmap_result *res = *result;
     if (!res) {
-        res = new pmap_result();
-        memset(&res->counts, 0, sizeof(res->counts));
-        memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
-        for (auto &e : res->kev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipEventCreateWithFlags(&res->sketched, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&res->done, hipEventDisableTiming));
-        HIP_TRY(hipHostMalloc((void **) &res->hc, sizeof(Counters), hipHostMallocDefault));
-        res->events = true;
-        *result = res;
+        if ((rc = new_result(result))) {
+            pmap_result_destroy(*result);
+            *result = nullptr;
+            return rc;
+        }
+        res = *result;
     }
     if (res->pending && (rc = pmap_map_wait(res))) return rc;   // the buffers are about to be reused
     const uint32_t last = prm->last_stage ? prm->last_stage : PMAP_STAGE_CLUSTER;
@@ -793,6 +841,147 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
     int rc = pmap_map_async(idx, rd, prm, result);
     if (rc) return rc;
     return pmap_map_wait(*result);
+}
+
+// ---------------------------------------------------------------------------
+// pmap_map without allocations
+
+static int new_result(pmap_result **out) {
+    pmap_result *res = new pmap_result();
+    memset(&res->counts, 0, sizeof(res->counts));
+    memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
+    *out = res;
+    for (auto &e : res->kev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&res->sketched, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&res->done, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **) &res->hc, sizeof(Counters), hipHostMallocDefault));
+    res->events = true;
+    return PMAP_OK;
+}
+
+// Once per device, with that device current (pmap_init): the address of this device's copy of the
+// scratch array, and everything else pmap_map_noalloc would otherwise have to create per call.
+static int noalloc_setup(int dev) {
+    if (dev < 0 || dev >= NA_MAX_DEVICES) return pmap_fail(PMAP_ELIMIT, "device number beyond the library's table");
+    NoAllocDevice &na = g_na[dev];
+    if (na.scratch) return PMAP_OK;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(pmap_scratch));
+    if (e != hipSuccess || !ptr)
+        return pmap_fail(PMAP_EHIP, std::string("hipGetSymbolAddress(pmap_scratch): ") + hipGetErrorString(e));
+    size_t bytes = 0;
+    HIP_TRY(hipGetSymbolSize(&bytes, HIP_SYMBOL(pmap_scratch)));
+    if (bytes < NA_SCRATCH_BYTES) return pmap_fail(PMAP_EHIP, "the scratch array is smaller than its layout");
+    HIP_TRY(hipHostMalloc((void **) &na.thr_stage, 4 * (NA_MAX_PRG + 64), hipHostMallocDefault));
+    int rc = new_result(&na.view);
+    if (rc) return rc;
+    unsigned char *base = (unsigned char *) ptr;
+    pmap_result *v = na.view;
+    v->state.view(base + NA_OFF_STATE, NA_OFF_GROUP - NA_OFF_STATE);
+    v->group_sum.view(base + NA_OFF_GROUP, NA_OFF_TILECNT - NA_OFF_GROUP);
+    v->tile_cnt.view(base + NA_OFF_TILECNT, NA_OFF_HBOUNDS - NA_OFF_TILECNT);
+    v->hbounds.view(base + NA_OFF_HBOUNDS, NA_OFF_THR - NA_OFF_HBOUNDS);
+    v->thr.view(base + NA_OFF_THR, NA_OFF_CSTART - NA_OFF_THR);
+    v->cstart.view(base + NA_OFF_CSTART, NA_OFF_HITS - NA_OFF_CSTART);
+    DevBuf *unsorted[5] = {&v->h_read, &v->h_key, &v->h_pos, &v->h_rank, &v->h_rec};
+    for (int i = 0; i < 5; ++i) unsorted[i]->view(base + NA_OFF_HITS + (size_t) i * 4 * NA_MAX_HITS, 4 * NA_MAX_HITS);
+    v->ents.view(base + NA_OFF_ENTS, 32 * NA_MAX_SLOTS);
+    // never used on this path (unfused mode, minimizer gather); empty views make any use fail instead of allocate
+    v->mkmer.view(nullptr, 0);
+    v->bsum.view(nullptr, 0);
+    v->scratch_total.view(nullptr, 0);
+    na.scratch = base;
+    return PMAP_OK;
+}
+
+extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd, const pmap_params_t *prm,
+                                const pmap_dev_out_t *out, pmap_counts_t *counts) {
+    if (!idx || !rd || !prm || !out || !counts) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (!g_ready) return pmap_fail(PMAP_EINVAL, "call pmap_init first: pmap_map_noalloc sets nothing up by itself");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NA_MAX_DEVICES || !g_na[dev].scratch)
+        return pmap_fail(PMAP_EINVAL, "pmap_init has not been called for the current device");
+    NoAllocDevice &na = g_na[dev];
+    pmap_result *res = na.view;
+    if (prm->k != idx->k) return pmap_fail(PMAP_EINVAL, "k differs from the k the index was built with");
+    if (prm->w < 1 || prm->w > (uint32_t) SK_MAX_W) return pmap_fail(PMAP_EINVAL, "w must be in [1,64]");
+    if ((prm->flags & PMAP_FLAG_UNFUSED) || (prm->last_stage && prm->last_stage != PMAP_STAGE_CLUSTER))
+        return pmap_fail(PMAP_EINVAL, "pmap_map_noalloc runs the whole path in its default mode only");
+    if (!idx->d_slots)
+        return pmap_fail(PMAP_EINVAL, "the index is not on the device: call pmap_index_upload_now first (this entry point does not allocate)");
+    if (!out->hit_read || !out->hit_key || !out->hit_pos || !out->hit_rank || !out->hit_rec || !out->cluster_rows)
+        return pmap_fail(PMAP_EINVAL, "null output buffer");
+    // capacities as the kernels' grids want them: whole blocks of the cluster kernels
+    const uint32_t hit_cap = (uint32_t) std::min<uint64_t>(out->hit_cap / CUT_BLOCK * (uint64_t) CUT_BLOCK, NA_MAX_HITS);
+    const uint32_t cl_cap = (uint32_t) std::min<uint64_t>(out->cluster_cap / KEEP_BLOCK * (uint64_t) KEEP_BLOCK, NA_MAX_CLUSTERS);
+    if (hit_cap == 0 || cl_cap == 0)
+        return pmap_fail(PMAP_EINVAL, "output buffers must hold at least 8192 hits and 1024 clusters");
+    uint32_t out_pos = 0, stride = 0;
+    sketch_kind(prm->w, prm->k, prm->flags, &out_pos, &stride);
+    const uint64_t n_tiles = ((uint64_t) rd->n_words * 16 + out_pos - 1) / out_pos;
+    if (n_tiles * stride > NA_MAX_SLOTS)
+        return pmap_fail(PMAP_ELIMIT, "batch too large for pmap_map_noalloc: its tiles need more than 2^20 entry slots "
+                                      "(about one million padded bases); split the batch or use pmap_map");
+    if (rd->n_reads > NA_MAX_READS) return pmap_fail(PMAP_ELIMIT, "more than 2^17 reads in a batch for pmap_map_noalloc");
+    if (idx->n_prg > NA_MAX_PRG) return pmap_fail(PMAP_ELIMIT, "more than 2^20 PRGs in the index for pmap_map_noalloc");
+    int rc;
+    if (res->pending && (rc = pmap_map_wait(res))) return rc;
+
+    memset(&res->counts, 0, sizeof(res->counts));
+    res->counts.n_reads = rd->n_reads;
+    res->counts.n_bases = rd->n_bases;
+    res->first_read_id = rd->first_read_id;
+    res->n_tiles = (uint32_t) n_tiles;
+    res->tile_stride = stride;
+    res->have_minimizers = false;
+    res->hit_cap = hit_cap;
+    res->cl_cap = cl_cap;
+    const size_t hb = 4 * (size_t) hit_cap;
+    res->s_read.view(out->hit_read, hb);
+    res->s_key.view(out->hit_key, hb);
+    res->s_pos.view(out->hit_pos, hb);
+    res->s_rank.view(out->hit_rank, hb);
+    res->s_rec.view(out->hit_rec, hb);
+    res->k_rows.view(out->cluster_rows, 32 * (size_t) cl_cap);
+    // per-prg size threshold (src/utils.cpp:211-213, 219-220) through the pinned staging buffer
+    if (res->thr_serial != idx->serial || res->thr_fraction != prm->fraction || res->thr_min != prm->min_cluster_size ||
+        res->thr_exp != prm->expected_kmers) {
+        HIP_TRY(hipStreamSynchronize(g_tail));        // an earlier copy out of the staging buffer has finished
+        for (uint32_t p = 0; p < idx->n_prg; ++p)
+            na.thr_stage[p] = pmap_threshold(idx->min_path_length[p], prm->expected_kmers, prm->fraction,
+                                             prm->min_cluster_size);
+        na.thr_stage[idx->n_prg] = 0;
+        HIP_TRY(hipMemcpyAsync(res->thr.p, na.thr_stage, 4 * ((size_t) idx->n_prg + 1), hipMemcpyHostToDevice, g_tail));
+        res->thr_serial = idx->serial;
+        res->thr_fraction = prm->fraction;
+        res->thr_min = prm->min_cluster_size;
+        res->thr_exp = prm->expected_kmers;
+    }
+    res->p_idx = idx;
+    res->p_rd = rd;
+    res->p_prm = *prm;
+    res->p_prm.profile = 0;
+    res->p_fused = true;
+    res->p_last = PMAP_STAGE_CLUSTER;
+    if ((rc = run_pipeline(res))) return rc;
+    HIP_TRY(hipEventSynchronize(res->done));
+    const Counters &hc = *res->hc;
+    if (hc.fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
+    counts->n_reads = rd->n_reads;
+    counts->n_bases = rd->n_bases;
+    counts->n_minimizers = hc.n_mini;
+    counts->n_hits = hc.n_hits;
+    counts->n_clusters_all = hc.n_cl;
+    counts->n_clusters = hc.n_kept;
+    memset(counts->ms, 0, sizeof(counts->ms));
+    if (hc.n_hits > hit_cap)
+        return pmap_fail(PMAP_ELIMIT, "the batch has more hits than the output buffers (or pmap_map_noalloc's 2^20) hold; "
+                                      "the counts say how many");
+    if (hc.n_cl > cl_cap)
+        return pmap_fail(PMAP_ELIMIT, "the batch has more clusters than the output buffers (or pmap_map_noalloc's 2^20) hold; "
+                                      "the counts say how many");
+    return PMAP_OK;
 }
 
 // every accessor of a result first waits for a run that is still in flight
