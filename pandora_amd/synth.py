@@ -67,6 +67,99 @@ def np_sketch(seq, w, k):
     return pos, h[pos], strand[pos]
 
 
+def _sliding(v, w, op):
+    """op over every window of w consecutive elements, by doubling: result[i] = op(v[i .. i+w-1])."""
+    cover = 1
+    while 2 * cover <= w:
+        v = op(v[:-cover], v[cover:])
+        cover *= 2
+    if cover < w:
+        v = op(v[:len(v) - (w - cover)], v[w - cover:])
+    return v
+
+
+def _kmers(c, k, n):
+    """Forward and reverse-complement k-mers (2 bits per base) at the first n positions of the code array c,
+    built by doubling: pieces of 1, 2, 4, ... bases are joined into k."""
+    c = c.astype(np.uint64)
+    f = {1: c}
+    r = {1: np.uint64(3) - c}
+    size = 1
+    while 2 * size <= k:
+        m = len(f[size]) - size
+        f[2 * size] = (f[size][:m] << np.uint64(2 * size)) | f[size][size:size + m]
+        r[2 * size] = r[size][:m] | (r[size][size:size + m] << np.uint64(2 * size))
+        size *= 2
+    fwd, rc, have = None, None, 0
+    while size >= 1:
+        if have + size <= k:
+            if fwd is None:
+                fwd, rc = f[size][:n], r[size][:n]
+            else:
+                fwd = (fwd << np.uint64(2 * size)) | f[size][have:have + n]
+                rc = rc | (r[size][have:have + n] << np.uint64(2 * have))
+            have += size
+        size //= 2
+    return fwd, rc
+
+
+def _sketch_chunk(seqs, first, w, k):
+    mask = (1 << (2 * k)) - 1
+    lens = np.array([len(x) for x in seqs], np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    cat = np.concatenate([np.asarray(x, np.uint8) for x in seqs]) if lens.sum() else np.zeros(0, np.uint8)
+    n = len(cat) - k + 1
+    if n < w or n <= 0:
+        return None
+    c = _CODE[cat]
+    bad = np.concatenate([[0], np.cumsum(c > 3)])
+    fwd, rc = _kmers(c & 3, k, n)
+    hf, hr = hash64_np(fwd, mask), hash64_np(rc, mask)
+    del fwd, rc
+    h = np.minimum(hf, hr)
+    strand = hf <= hr
+    del hf, hr
+    loc = np.repeat(np.arange(len(seqs)), lens)                   # sequence of every base
+    ok_seq = (lens + 1 >= w + k) & (bad[starts[1:]] == bad[starts[:-1]])
+    kvalid = (loc[:n] == loc[k - 1:]) & ok_seq[loc[:n]]           # a k-mer of one sketchable sequence
+    win = _sliding(h, w, np.minimum)                              # min of window i = k-mers i .. i+w-1
+    if win is h:
+        win = h.copy()
+    wvalid = kvalid[:len(win)] & kvalid[w - 1:] & (loc[:len(win)] == loc[w - 1:w - 1 + len(win)])
+    win[~wvalid] = 0
+    pad = np.zeros(w - 1, np.uint64)
+    best = _sliding(np.concatenate([pad, win, pad]), w, np.maximum)  # over the windows that contain k-mer j
+    at = np.nonzero(kvalid & (best == h))[0]
+    return loc[at] + first, at - starts[loc[at]], h[at], strand[at].astype(np.uint8)
+
+
+def np_sketch_many(seqs, w, k, chunk_bases=1 << 23, threads=None):
+    """np_sketch of every sequence of a list, computed over concatenated chunks (a few numpy passes per chunk
+    instead of per sequence; chunks on several threads, numpy releases the interpreter lock).  Returns flat
+    arrays (sequence index, position, hash, strand) in (sequence, position) order."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = []
+    i = 0
+    while i < len(seqs):
+        j, tot = i, 0
+        while j < len(seqs) and (j == i or tot + len(seqs[j]) <= chunk_bases):
+            tot += len(seqs[j])
+            j += 1
+        chunks.append((i, j))
+        i = j
+    if threads is None:
+        try:
+            threads = min(len(os.sched_getaffinity(0)), 16)
+        except Exception:
+            threads = 4
+    with ThreadPoolExecutor(max(1, min(threads, len(chunks) or 1))) as ex:
+        parts = [p for p in ex.map(lambda ab: _sketch_chunk(seqs[ab[0]:ab[1]], ab[0], w, k), chunks) if p is not None]
+    if not parts:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    return tuple(np.concatenate([p[f] for p in parts]) for f in range(4))
+
+
 class SynthIndex:
     """Flat arrays of an index (the layout pmap_index_desc_t and the oracle take)."""
 
@@ -92,21 +185,13 @@ def build_index(loci, w, k, rng=None, split_paths=0.0):
     """Index of linear loci.  With split_paths > 0 that fraction of records gets its path [j, j+k)
     written as several intervals separated by zero-length or shifted pieces, the shape paths take in
     PRGs with variant sites (include/prg/path.h); coordinates stay unique per locus."""
-    prg_l, key_l, pos_l, strand_l, knode_l = [], [], [], [], []
-    mpl = np.zeros(len(loci), np.uint32)
-    for p, locus in enumerate(loci):
-        pos, h, s = np_sketch(locus, w, k)
-        mpl[p] = len(pos) + 1          # linear kmer graph: #minimizer nodes + 1 (src/kmergraph.cpp:664-684)
-        prg_l.append(np.full(len(pos), p, np.uint32))
-        key_l.append(h)
-        pos_l.append(pos.astype(np.uint32))
-        strand_l.append(s)
-        knode_l.append(np.arange(1, len(pos) + 1, dtype=np.uint32))
-    prg = np.concatenate(prg_l) if prg_l else np.zeros(0, np.uint32)
-    key = np.concatenate(key_l) if key_l else np.zeros(0, np.uint64)
-    pos = np.concatenate(pos_l) if pos_l else np.zeros(0, np.uint32)
-    strand = np.concatenate(strand_l) if strand_l else np.zeros(0, np.uint8)
-    knode = np.concatenate(knode_l) if knode_l else np.zeros(0, np.uint32)
+    seq_i, pos, key, strand = np_sketch_many(loci, w, k)
+    per_locus = np.bincount(seq_i, minlength=len(loci)).astype(np.int64)
+    mpl = (per_locus + 1).astype(np.uint32)    # linear kmer graph: #minimizer nodes + 1 (src/kmergraph.cpp:664-684)
+    prg = seq_i.astype(np.uint32)
+    pos = pos.astype(np.uint32)
+    first = np.concatenate([[0], np.cumsum(per_locus)])[:-1]
+    knode = (np.arange(len(prg), dtype=np.int64) - first[seq_i] + 1).astype(np.uint32)
     # group by key (stable: records of one key stay in (prg, position) order, as add_record appends them)
     order = np.argsort(key, kind="stable")
     key, prg, pos, strand, knode = key[order], prg[order], pos[order], strand[order], knode[order]
@@ -140,8 +225,171 @@ def build_index(loci, w, k, rng=None, split_paths=0.0):
     return SynthIndex(k, w, ukeys, rec_off, prg, knode, strand, path_off, ivs, ivl, mpl)
 
 
-def make_loci(n_loci, rng, median_len=1000, min_len=300, max_len=5000, dup_frac=0.02, dup_div=0.01):
-    """Random loci, lognormal length; dup_frac of them are diverged copies of another locus (shared k-mers)."""
+class VariantLocus:
+    """A locus with variant sites, the shape of a PRG with one level of bubbles: plain sequence pieces
+    alternate with sites, each site a list of alleles (an allele may be empty).  Coordinates are those of
+    the PRG string `pre 5 allele 6 allele 5 post ...` (test/test_cases/prg0123.fa), markers included."""
+
+    def __init__(self, plains, sites):
+        assert len(plains) == len(sites) + 1
+        self.plains, self.sites = plains, sites
+
+    def haplotype(self, choice):
+        """Sequence with allele choice[i] (clipped to the site's allele count) at site i."""
+        parts = [self.plains[0]]
+        for i, al in enumerate(self.sites):
+            parts.append(al[min(int(choice[i]), len(al) - 1)])
+            parts.append(self.plains[i + 1])
+        return np.concatenate(parts)
+
+    def prg_string(self):
+        out = [bytes(self.plains[0])]
+        for i, al in enumerate(self.sites):
+            odd, even = b" %d " % (5 + 2 * i), b" %d " % (6 + 2 * i)
+            out.append(odd + even.join(bytes(a) for a in al) + odd)
+            out.append(bytes(self.plains[i + 1]))
+        return b"".join(out)
+
+    def segments(self, h):
+        """(bases, prg_start) of every piece of haplotype h (allele min(h, n-1) at every site), in order."""
+        segs, c = [(self.plains[0], 0)], len(self.plains[0])
+        for i, al in enumerate(self.sites):
+            mo, me = len(str(5 + 2 * i)) + 2, len(str(6 + 2 * i)) + 2
+            c += mo
+            pick = min(h, len(al) - 1)
+            for a, allele in enumerate(al):
+                if a == pick:
+                    segs.append((allele, c))
+                c += len(allele) + (me if a + 1 < len(al) else mo)
+            segs.append((self.plains[i + 1], c))
+            c += len(self.plains[i + 1])
+        return segs
+
+
+def make_variant_loci(loci, rng, var_frac=0.8, site_every=100, min_gap=48, max_alleles=3):
+    """Turns linear loci into loci with variant sites on var_frac of them: a site about every site_every
+    bases (never closer than min_gap, so that a (w, k) window with w + k - 1 <= min_gap meets at most one
+    site), SNPs mostly, some short insertions and deletions, two or three alleles."""
+    out = []
+    for seq in loci:
+        L = len(seq)
+        if rng.random() >= var_frac or L < 3 * min_gap:
+            out.append(VariantLocus([seq], []))
+            continue
+        plains, sites, at = [], [], 0
+        p = int(rng.integers(min_gap, min_gap + site_every))
+        while p + 4 + min_gap < L:
+            kind = rng.random()
+            if kind < 0.7:                                  # SNP
+                ref = seq[p:p + 1]
+                alts = [b for b in _ACGT if b != ref[0]]
+                rng.shuffle(alts)
+                n_al = 2 if rng.random() < 0.8 else min(3, max_alleles)
+                alleles = [ref.copy()] + [np.array([alts[i]], np.uint8) for i in range(n_al - 1)]
+                used = 1
+            elif kind < 0.85:                               # insertion after one reference base
+                ref = seq[p:p + 1]
+                alleles = [ref.copy(), np.concatenate([ref, random_dna(int(rng.integers(1, 4)), rng)])]
+                used = 1
+            else:                                           # deletion of 1..3 bases: the other allele is empty
+                used = int(rng.integers(1, 4))
+                alleles = [seq[p:p + used].copy(), np.zeros(0, np.uint8)]
+            plains.append(seq[at:p].copy())
+            sites.append(alleles)
+            at = p + used
+            p = at + int(rng.integers(min_gap, 2 * site_every - min_gap + 1))
+        plains.append(seq[at:].copy())
+        out.append(VariantLocus(plains, sites))
+    return out
+
+
+def build_variant_index(vloci, w, k, max_alleles=3):
+    """Index of loci with variant sites: the records `pandora index` writes are the minimizer k-mers of every
+    path through the PRG (src/localPRG.cpp:333-540).  With sites at least w + k - 1 apart a window meets at
+    most one site, so the windows of the haplotypes "allele h at every site", h = 0 .. max_alleles-1, are all
+    the windows there are: the index is the union of those haplotypes' sketches, each k-mer with its path in
+    PRG coordinates (one interval per piece it touches; an empty allele inside gives a zero-length
+    interval), duplicates of the same (prg, path, strand) dropped as Index::add_record does
+    (src/index.cpp:20-37)."""
+    n_loci = len(vloci)
+    hap_seqs, seg_hap_start, seg_len, seg_prg, seg_off, base_seg = [], [], [], [], [0], []
+    for v in vloci:
+        for h in range(max_alleles if v.sites else 1):
+            segs = v.segments(h)
+            lens = np.array([len(b) for b, _ in segs], np.int64)
+            hap_seqs.append(np.concatenate([b for b, _ in segs]))
+            seg_hap_start.append(np.concatenate([[0], np.cumsum(lens)[:-1]]))
+            seg_len.append(lens)
+            seg_prg.append(np.array([c for _, c in segs], np.int64))
+            base_seg.append(np.repeat(np.arange(len(segs), dtype=np.int32) + np.int32(seg_off[-1]), lens))
+            seg_off.append(seg_off[-1] + len(segs))
+    hap_locus = np.concatenate([np.full(max_alleles if v.sites else 1, i) for i, v in enumerate(vloci)]) \
+        if n_loci else np.zeros(0, np.int64)
+    hap_first = np.concatenate([[1] + [0] * ((max_alleles if v.sites else 1) - 1) for v in vloci]) \
+        if n_loci else np.zeros(0, np.int64)
+    base_off = np.concatenate([[0], np.cumsum([len(x) for x in hap_seqs])]).astype(np.int64)
+    seg_hap_start = np.concatenate(seg_hap_start) if seg_hap_start else np.zeros(0, np.int64)
+    seg_len = np.concatenate(seg_len) if seg_len else np.zeros(0, np.int64)
+    seg_prg = np.concatenate(seg_prg) if seg_prg else np.zeros(0, np.int64)
+    base_seg = np.concatenate(base_seg) if base_seg else np.zeros(0, np.int32)
+
+    q, pos, key, strand = np_sketch_many(hap_seqs, w, k)
+    prg = hap_locus[q]
+    s0 = base_seg[base_off[q] + pos].astype(np.int64)
+    s1 = base_seg[base_off[q] + pos + k - 1].astype(np.int64)
+    n_iv = s1 - s0 + 1
+    assert len(n_iv) == 0 or n_iv.max() <= 3, "sites closer than k: a k-mer touches more than three pieces"
+    c0 = seg_prg[s0] + (pos - seg_hap_start[s0])
+    c_last = seg_prg[s1] + (pos + k - 1 - seg_hap_start[s1])
+    mid = np.where(n_iv == 3, seg_prg[np.minimum(s0 + 1, len(seg_prg) - 1)], 0xFFFFFFFF)
+    # drop the k-mers that several haplotypes share: same prg, same path, same strand (then also the same key)
+    a = (prg.astype(np.uint64) << np.uint64(32)) | c0.astype(np.uint64)
+    b = (c_last.astype(np.uint64) << np.uint64(33)) | (mid.astype(np.uint64) << np.uint64(1)) | strand.astype(np.uint64)
+    order = np.lexsort((b, a))
+    keep = np.ones(len(order), bool)
+    keep[1:] = (a[order][1:] != a[order][:-1]) | (b[order][1:] != b[order][:-1])
+    sel = order[keep]                                       # in (prg, path) order
+    q, pos, key, strand, prg, s0, s1, n_iv, c0 = (x[sel] for x in (q, pos, key, strand, prg, s0, s1, n_iv, c0))
+    per_locus = np.bincount(prg, minlength=n_loci).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(per_locus)])[:-1]
+    knode = (np.arange(len(prg), dtype=np.int64) - first[prg] + 1).astype(np.uint32)
+    # min_path_length is an input of the path: here the node count of the first haplotype + 1, what the
+    # reference's computation gives for a linear graph
+    n_first = np.bincount(prg[hap_first[q] == 1], minlength=n_loci)
+    mpl = (n_first + 1).astype(np.uint32)
+    # intervals
+    n = len(prg)
+    path_off = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+    ivs = np.zeros(int(path_off[-1]), np.uint32)
+    ivl = np.zeros(int(path_off[-1]), np.uint32)
+    for t in range(3):
+        m = n_iv > t
+        seg = s0[m] + t
+        lo = np.maximum(pos[m], seg_hap_start[seg])
+        hi = np.minimum(pos[m] + k, seg_hap_start[seg] + seg_len[seg])
+        ivs[path_off[:-1][m] + t] = seg_prg[seg] + (lo - seg_hap_start[seg])
+        ivl[path_off[:-1][m] + t] = hi - lo
+    # group by key
+    order = np.argsort(key, kind="stable")
+    ukeys, firstk = np.unique(key[order], return_index=True)
+    rec_off = np.concatenate([firstk, [n]]).astype(np.uint64)
+    new_off = np.concatenate([[0], np.cumsum(n_iv[order])]).astype(np.int64)
+    gather = np.repeat(path_off[:-1][order] - new_off[:-1], n_iv[order]) + np.arange(int(new_off[-1]))
+    return SynthIndex(k, w, ukeys, rec_off, prg[order].astype(np.uint32), knode[order], strand[order],
+                      new_off.astype(np.uint64), ivs[gather], ivl[gather], mpl)
+
+
+def make_variant_genome(vloci, rng, spacer=(200, 2000)):
+    """As make_genome, with a random allele at every site of every locus."""
+    loci = [v.haplotype(rng.integers(0, 3, len(v.sites))) for v in vloci]
+    return make_genome(loci, rng, spacer)
+
+
+def make_loci(n_loci, rng, median_len=1000, min_len=300, max_len=5000, dup_frac=0.02, dup_div=0.01,
+              family_frac=0.0, family_max=10, family_div=0.005):
+    """Random loci, lognormal length; dup_frac of them are diverged copies of another locus (shared k-mers).
+    family_frac of the loci come in families of 2..family_max diverged copies of one founder (paralogous
+    genes, insertion sequences): their k-mers are index keys with several records."""
     lens = np.clip(rng.lognormal(np.log(median_len), 0.35, n_loci), min_len, max_len).astype(np.int64)
     loci = [random_dna(int(l), rng) for l in lens]
     n_dup = int(n_loci * dup_frac)
@@ -153,6 +401,15 @@ def make_loci(n_loci, rng, median_len=1000, min_len=300, max_len=5000, dup_frac=
         mut = rng.random(len(src)) < dup_div
         src[mut] = random_dna(int(mut.sum()), rng)
         loci[b] = src
+    at, n_fam = 0, int(n_loci * family_frac)
+    while at + 1 < n_fam:
+        size = min(int(rng.integers(2, family_max + 1)), n_fam - at)
+        for m in range(1, size):
+            src = loci[at].copy()
+            mut = rng.random(len(src)) < family_div
+            src[mut] = random_dna(int(mut.sum()), rng)
+            loci[at + m] = src
+        at += size
     return loci
 
 
@@ -220,46 +477,45 @@ def simulate_reads(genome, n_reads, rng, mean_len=10000, sigma=0.5, e_rate=0.11,
 def workload(name, seed=1, scale=1.0, shard=0):
     """Named synthetic workloads.  Returns (SynthIndex, bases, offsets, params dict).
 
-    nanopore_1k   1 000 loci, 10 000 reads of ~10 kb at 11 % error, w=14 k=15 (scale multiplies reads)
-    illumina_1k   1 000 loci, 150 bp reads at 0.1 % substitutions, w=14 k=15, illumina thresholds
-    illumina_w1   the same with w=1 (dense minimizers; the reference's threshold rejects every cluster)
-    nanopore_20k  20 000 loci, 15 000 nanopore reads (30x of the genome), w=14 k=15
-    illumina_20k_w1  20 000 loci, 400 000 reads of 150 bp, w=1 k=15
-    nanopore_200k 200 000 loci (27 M keys, multi-GB table), 15 000 nanopore reads, w=14 k=15
+    nanopore_1k       1 000 loci, 80 % of them with variant sites about every 100 bases (SNPs, short indels:
+                      index paths of one to three intervals), 2 % diverged duplicates; 10 000 reads of ~10 kb
+                      at 11 % error sampled from a genome with a random allele at every site; w=14 k=15
+                      (scale multiplies the reads)
+    nanopore_1k_linear    the same loci without variant sites (every path one interval)
+    nanopore_1k_families  variant sites, and 50 % of the loci in families of 2..10 paralogs: 1.5 records per
+                      index key on average, up to 10
+    illumina_1k       the nanopore_1k index, 150 bp reads at 0.1 % substitutions, w=14 k=15, illumina thresholds
+    illumina_w1       the same with w=1 (dense minimizers; the reference's threshold rejects every cluster)
+    nanopore_20k      20 000 loci with variant sites, 15 000 nanopore reads (30x of the genome), w=14 k=15
+    illumina_20k_w1   20 000 loci, 400 000 reads of 150 bp, w=1 k=15
+    nanopore_200k     200 000 linear loci (27 M keys, multi-GB table), 15 000 nanopore reads, w=14 k=15
 
     `shard` selects an independent batch of reads over the same index and genome (one per GPU rank).
     """
     rng = np.random.default_rng(seed)
-    if name == "nanopore_1k":
-        w, k, n_loci, n_reads = 14, 15, 1000, int(10000 * scale)
-        loci = make_loci(n_loci, rng)
+    ill = name.startswith("illumina")
+    w = 1 if name.endswith("_w1") else 14
+    k = 15
+    n_loci = 200000 if "200k" in name else 20000 if "20k" in name else 1000
+    linear = name.endswith("_linear") or "200k" in name
+    if name not in ("nanopore_1k", "nanopore_1k_linear", "nanopore_1k_families", "illumina_1k", "illumina_w1",
+                    "nanopore_20k", "nanopore_20k_linear", "illumina_20k_w1", "nanopore_200k"):
+        raise ValueError(name)
+    loci = make_loci(n_loci, rng, family_frac=0.5 if name.endswith("_families") else 0.0)
+    if linear:
         idx = build_index(loci, w, k)
         genome = make_genome(loci, np.random.default_rng(seed + 1))
+    else:
+        vloci = make_variant_loci(loci, np.random.default_rng(seed + 5))
+        idx = build_variant_index(vloci, w, k)
+        genome = make_variant_genome(vloci, np.random.default_rng(seed + 1))
+    if ill:
+        n_reads = int((400000 if "20k" in name else 200000) * scale)
+        bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 3, shard]), fixed_len=150,
+                                    e_rate=0.001)
+        prm = dict(w=w, k=k, max_diff=2 * k + 1, e_rate=0.001, min_cluster_size=10, illumina=True)
+    else:
+        n_reads = int((10000 if n_loci == 1000 else 15000) * scale)
         bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 2, shard]))
         prm = dict(w=w, k=k, max_diff=250, e_rate=0.11, min_cluster_size=10, illumina=False)
-    elif name in ("illumina_1k", "illumina_w1"):
-        w = 1 if name == "illumina_w1" else 14
-        k, n_loci, n_reads = 15, 1000, int(200000 * scale)
-        loci = make_loci(n_loci, rng)
-        idx = build_index(loci, w, k)
-        genome = make_genome(loci, np.random.default_rng(seed + 1))
-        bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 3, shard]), fixed_len=150, e_rate=0.001)
-        prm = dict(w=w, k=k, max_diff=2 * k + 1, e_rate=0.001, min_cluster_size=10, illumina=True)
-    elif name in ("nanopore_20k", "illumina_20k_w1", "nanopore_200k"):
-        # E. coli-scale index: 20 000 loci, a 128 MB slot table (beyond every cache but the Infinity Cache);
-        # multi-species scale: 200 000 loci, a 2 GB slot table in HBM
-        ill = name == "illumina_20k_w1"
-        w, k, n_loci = (1 if ill else 14), 15, (200000 if name == "nanopore_200k" else 20000)
-        loci = make_loci(n_loci, rng)
-        idx = build_index(loci, w, k)
-        genome = make_genome(loci, np.random.default_rng(seed + 1))
-        if ill:
-            bases, off = simulate_reads(genome, int(400000 * scale), np.random.default_rng([seed + 3, shard]),
-                                        fixed_len=150, e_rate=0.001)
-            prm = dict(w=w, k=k, max_diff=2 * k + 1, e_rate=0.001, min_cluster_size=10, illumina=True)
-        else:
-            bases, off = simulate_reads(genome, int(15000 * scale), np.random.default_rng([seed + 2, shard]))
-            prm = dict(w=w, k=k, max_diff=250, e_rate=0.11, min_cluster_size=10, illumina=False)
-    else:
-        raise ValueError(name)
     return idx, bases, off, prm
