@@ -3,11 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the whole device path (pmap_map: sketch, probe/emit, sort, cluster cut) over
-one batch of synthetic reads that is already resident in HBM (2-bit packed).  At N > 1 every rank
-maps its own, equally sized batch against a replicated index (reads shard, no collective on the data
-path); the value is the total number of read bases all ranks mapped per second.  Rank 0 prints one
-JSON line.
+A step is one pass of the whole device path (pmap_map: sketch with the index lookup fused in, hit
+emission, sort, cluster cut) over one batch of synthetic reads that is already resident in HBM (2-bit
+packed).  At N > 1 every rank maps its own, equally sized batch against a replicated index (reads shard,
+no collective on the data path); the value is the total number of read bases all ranks mapped per
+second.  Rank 0 prints one JSON line.  At N = 1 the same run then measures the other workloads (dense
+Illumina sketches, the 20 000- and 200 000-locus indexes, an index with several records per key) and
+reports them under "other_workloads".
 """
 import argparse
 import json
@@ -21,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4    # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 
 # The library keeps four streams busy (two for sketch kernels, one for everything after them, one for
 # uploads); torch and the collective library bring their own.  With the HIP default of 4 hardware queues
@@ -33,33 +36,29 @@ try:
 except ValueError:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
-# kernels of each phase (names of pmap_kernel_name)
+# kernels of each phase (names of pmap_kernel_name).  The index lookup of add_read_hits runs inside the
+# sketch kernel, so "sketch+probe" is one kernel; "emit" is the construction of the hits.
 PHASES = {
-    "sketch": ["sketch"],          # fused mode: the index lookup runs inside this kernel
-    "probe": ["probe", "scatter"],
+    "sketch+probe": ["sketch", "probe"],
+    "emit": ["scatter"],
     "sort": ["sort_rank"],
     "cluster": ["cluster_cut", "cluster_keep"],
 }
 
+ALGO_DEF = ("B read bases, M minimizers, H hits, C clusters before the size threshold.  sketch+probe: B/4 "
+            "(2-bit packed reads) + 16 M (a minimizer: u64 hash, u32 position, u32 read/strand) + 16 M (one 16-byte "
+            "table slot per looked-up minimizer); emit: 36 H (16-byte record read, 20-byte hit written); sort: 40 H "
+            "(every 20-byte hit read once and written once); cluster: 24 H + 28 C")
 
-def algorithmic_bytes(cn, n_prg, n_reads_batch):
-    """Algorithmic bytes of each phase for one launch of the path over one batch:
-    B read bases, M minimizers, H hits, C clusters.
-      sketch   B/4 (2-bit packed read) + 16 M (u64 hash + u32 position + u32 read/strand written)
-      probe    2 (16 M + 16 M) (minimizer re-read + one 16-byte slot per probe, count and scatter pass)
-               + H (16 + 20) (16-byte record read, 20-byte hit written)
-      sort     2 * 20 * H * P, P = 8-bit passes over the (read, prg, strand) key
-      cluster  20 H read + 4 H flag/id written + 28 C
-    """
+
+def algorithmic_bytes(cn):
     B, M, H, C = cn["n_bases"], cn["n_minimizers"], cn["n_hits"], cn["n_clusters_all"]
-    bits = max(1, int(np.ceil(np.log2(max(n_reads_batch, 2))))) + max(1, int(np.ceil(np.log2(max(n_prg, 2))))) + 1
-    P = int(np.ceil(bits / 8))
     return {
-        "sketch": B / 4 + 16 * M,
-        "probe": 2 * (16 * M + 16 * M) + H * 36,
-        "sort": 2 * 20 * H * P,
-        "cluster": 20 * H + 4 * H + 28 * C,
-    }, P
+        "sketch+probe": B / 4 + 16 * M + 16 * M,
+        "emit": 36 * H,
+        "sort": 40 * H,
+        "cluster": 24 * H + 28 * C,
+    }
 
 
 def cpu_baseline(si, bases, offsets, prm, fraction, budget_s=10.0, threads_budget_s=5.0):
@@ -126,6 +125,125 @@ def cpu_baseline(si, bases, offsets, prm, fraction, budget_s=10.0, threads_budge
     return out
 
 
+class Workload:
+    """One synthetic workload resident on the GPU: index, one batch of reads, the call that maps it."""
+
+    def __init__(self, api, synth, name, scale, shard, last_stage=0):
+        self.api, self.name = api, name
+        self.si, self.bases, self.offsets, self.prm = synth.workload(name, seed=1, scale=scale, shard=shard)
+        si, prm = self.si, self.prm
+        self.fraction = api.fraction(prm["e_rate"], prm["k"])
+        self.expected = 150 * 2 // prm["w"] if prm["illumina"] else 0xFFFFFFFF
+        self.last_stage = last_stage
+        self.gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                                     si.iv_start, si.iv_len, si.min_path_length)
+        self.gidx.upload()
+        t0 = time.perf_counter()
+        self.reads = api.Reads(self.bases, self.offsets)
+        self.upload_s = time.perf_counter() - t0
+
+    def step(self, res, profile, wait=True):
+        p = self.prm
+        return self.api.map_reads(self.gidx, self.reads, p["w"], p["k"], p["max_diff"], self.fraction,
+                                  p["min_cluster_size"], self.expected, profile=profile, result=res, wait=wait,
+                                  last_stage=self.last_stage)
+
+    def close(self):
+        self.reads.close()
+        self.gidx.close()
+
+
+def timed_steps(wl, steps, depth, prof, ring, before=None, after=None):
+    """`steps` steps with `depth` of them in flight (pmap_map_async / pmap_map_wait; depth 1 = blocking calls).
+    Returns (seconds, sum of the sketch kernel's event times in ms, last result)."""
+    sketch_ms = 0.0
+    inflight = [False] * depth
+
+    def retire(j):
+        nonlocal sketch_ms
+        ring[j].wait()
+        inflight[j] = False
+        if prof:
+            sketch_ms += ring[j].kernel_ms()["sketch"]
+
+    if before:
+        before()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        j = i % depth
+        if inflight[j]:
+            retire(j)
+        ring[j] = wl.step(ring[j], prof, wait=False)
+        inflight[j] = True
+    for j in range(depth):
+        if inflight[j]:
+            retire(j)
+    if after:
+        after()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sketch_ms, ring[(steps - 1) % depth] if steps else ring[0]
+
+
+def kernel_table(wl, res, steps):
+    """Per-kernel milliseconds per step from an untimed pass with events on every kernel, one step at a time
+    (each kernel with the machine to itself)."""
+    kernel_ms = {}
+    for _ in range(steps):
+        res = wl.step(res, 1)
+        for name, ms in res.kernel_ms().items():
+            kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
+    return {k: v / max(steps, 1) for k, v in kernel_ms.items()}, res
+
+
+def phase_table(kernel_ms, algo):
+    phases = {}
+    for ph, ks in PHASES.items():
+        ms = sum(kernel_ms.get(k, 0.0) for k in ks)
+        gbps = (algo[ph] / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        phases[ph] = {"ms": ms, "algorithmic_bytes": algo[ph], "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+                      "kernels": {k: kernel_ms.get(k, 0.0) for k in ks if kernel_ms.get(k, 0.0) > 0}}
+        # a phase cannot move its algorithmic bytes faster than HBM delivers them unless they came from a cache
+        if gbps > HBM_PEAK_GBS:
+            phases[ph]["note"] = "above the HBM peak: this phase's working set is served by the caches on this workload"
+    return phases
+
+
+def other_workload(api, synth, name, scale, depth, budget_s):
+    """Throughput and per-kernel table of one more workload (N = 1 only)."""
+    t0 = time.perf_counter()
+    wl = Workload(api, synth, name, scale, 0)
+    ring = [None] * depth
+    for i in range(max(3, depth)):
+        ring[i % depth] = wl.step(ring[i % depth], 0)
+    one, _, res = timed_steps(wl, depth, depth, 0, ring)
+    steps = int(max(20, min(400, budget_s / max(one / depth, 1e-5))))
+    elapsed, _, res = timed_steps(wl, steps, depth, 0, ring)
+    cn = res.counts()
+    kernel_ms, res = kernel_table(wl, res, 10)
+    algo = algorithmic_bytes(cn)
+    info = wl.gidx.info()
+    sk = kernel_ms.get("sketch", 0.0)
+    out = {
+        "workload": "%s: %d loci, %d keys, %d records, table %.0f MB, filter bits/key %d; %d reads, w=%d k=%d"
+                    % (name, wl.si.n_prg, info["n_keys"], info["n_recs"], info["table_slots"] * 32 / 1e6,
+                       info["filter_bits_per_key"], cn["n_reads"], wl.prm["w"], wl.prm["k"]),
+        "bases_per_s": cn["n_bases"] * steps / elapsed, "hits_per_s": cn["n_hits"] * steps / elapsed,
+        "ms_per_step": elapsed / steps * 1e3, "steps": steps, "steps_in_flight": depth,
+        "bases": cn["n_bases"], "minimizers": cn["n_minimizers"], "hits": cn["n_hits"],
+        "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],
+        "kernel_ms_alone": kernel_ms, "phases": phase_table(kernel_ms, algo),
+        # hash-probe bandwidth: minimizers looked up per second of the kernel that does the lookups
+        "lookups_per_s": (cn["n_minimizers"] / (sk * 1e-3)) if sk > 0 else 0.0,
+        "setup_s": None,
+    }
+    for r in ring:
+        if r is not None:
+            r.close()
+    wl.close()
+    out["setup_s"] = time.perf_counter() - t0 - elapsed
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +254,11 @@ def main():
     ap.add_argument("--workload", default="nanopore_1k")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--others", default="default",
+                    help="comma-separated workloads measured after the headline one at N = 1 ('none' = skip; default: "
+                         "nanopore_1k_linear, nanopore_1k_families, illumina_1k, illumina_w1, nanopore_20k, "
+                         "illumina_20k_w1, nanopore_200k while the time budget lasts)")
+    ap.add_argument("--others-budget", type=float, default=240.0, help="seconds the other workloads may take in all")
     ap.add_argument("--depth", type=int, default=3,
                     help="steps in flight (1 = blocking pmap_map); with 3 both sketch streams always hold a kernel "
                          "while the host waits for a result, and the tail kernels of a step run next to the sketch "
@@ -180,81 +303,39 @@ def main():
     from pandora_amd import api, synth
     pandora_amd.init(device)
 
-    # same index on every rank (replicated), a different shard of reads per rank
-    def progress(msg):     # a big workload takes minutes to synthesise: say so on stderr
+    def progress(msg):     # a big workload takes a while to synthesise: say so on stderr
         if rank == 0:
             print("[bench] %s (%.0f s)" % (msg, time.perf_counter() - t_start), file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
     progress("synthesising workload %s" % args.workload)
-    si, bases, offsets, prm = synth.workload(args.workload, seed=1, scale=args.scale, shard=rank)
-    progress("flattening the index: %d keys, %d records" % (len(si.keys), len(si.rec_prg)))
-    fraction = api.fraction(prm["e_rate"], prm["k"])
-    expected = 0xFFFFFFFF
-    if prm["illumina"]:
-        expected = 150 * 2 // prm["w"]
-    gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
-                            si.iv_start, si.iv_len, si.min_path_length)
-    progress("index on the device, uploading %d bases" % len(bases))
-    t0 = time.perf_counter()
-    reads = api.Reads(bases, offsets)
-    upload_s = time.perf_counter() - t0
-
-    def step(res, profile, wait=True):
-        return api.map_reads(gidx, reads, prm["w"], prm["k"], prm["max_diff"], fraction, prm["min_cluster_size"],
-                             expected, profile=profile, result=res, wait=wait, last_stage=args.last_stage)
+    # same index on every rank (replicated), a different shard of reads per rank
+    wl = Workload(api, synth, args.workload, args.scale, rank, args.last_stage)
+    si, prm = wl.si, wl.prm
+    progress("index (%d keys, %d records) and %d bases on the device" % (len(si.keys), len(si.rec_prg), len(wl.bases)))
 
     # `depth` result objects take turns, so that the host enqueues a step while the GPU runs the one before
-    # (pmap_map_async / pmap_map_wait); depth 1 is the blocking pmap_map
     depth = max(1, args.depth)
     ring = [None] * depth
     for i in range(max(args.warmup, depth)):
-        ring[i % depth] = step(ring[i % depth], 0)
+        ring[i % depth] = wl.step(ring[i % depth], 0)
 
     def sync():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier(device_ids=[device]) if backend == "nccl" else dist.barrier()
 
-    kernel_ms, sketch_ms = {}, 0.0
-    sync()
-    t0 = time.perf_counter()
+    # profile=2: one pair of HIP events rides on the dispatch of the sketch kernel (the dominant one) on the
+    # library's stream, inside the timed region
     prof = 0 if args.no_kernel_events else 2
-    inflight = [False] * depth
-
-    def retire(j):
-        nonlocal sketch_ms
-        ring[j].wait()
-        inflight[j] = False
-        if prof:
-            sketch_ms += ring[j].kernel_ms()["sketch"]
-
-    for i in range(args.steps):
-        # profile=2: one pair of HIP events rides on the dispatch of the sketch kernel (the dominant one)
-        # on the library's stream, inside the timed region
-        j = i % depth
-        if inflight[j]:
-            retire(j)
-        ring[j] = step(ring[j], prof, wait=False)
-        inflight[j] = True
-    for j in range(depth):
-        if inflight[j]:
-            retire(j)
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, sketch_ms, res = timed_steps(wl, args.steps, depth, prof, ring, before=sync, after=sync)
     elapsed_local = elapsed
-    res = ring[(args.steps - 1) % depth] if args.steps else ring[0]
     cn = res.counts()
-    # second, untimed pass with events on every kernel, for the per-phase table
-    for _ in range(args.steps):
-        res = step(res, 1)
-        for name, ms in res.kernel_ms().items():
-            kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
-    # the sketch kernel's time when it has the machine to itself (second pass, one step at a time); in the timed
-    # region above it shares the CUs with the tail kernels of the step before, so its event time there is longer
+    # second, untimed pass with events on every kernel, for the per-phase table: one step at a time, every
+    # kernel with the machine to itself (in the timed region the sketch kernels of two steps and the tail
+    # kernels of a third share the CUs, so a launch lasts longer there)
+    kernel_ms, res = kernel_table(wl, res, min(args.steps, 200))
     sketch_alone_ms = kernel_ms.get("sketch", 0.0)
-    if prof:
-        kernel_ms["sketch"] = sketch_ms
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -267,46 +348,47 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        kernel_ms = {k: v / steps for k, v in kernel_ms.items()}
-        algo, P = algorithmic_bytes(cn, si.n_prg, cn["n_reads"])
-        phases = {}
-        for ph, ks in PHASES.items():
-            ms = sum(kernel_ms.get(k, 0.0) for k in ks)
-            phases[ph] = {"ms": ms, "algorithmic_bytes": algo[ph],
-                          "GBps": (algo[ph] / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
-                          "kernels": {k: kernel_ms.get(k, 0.0) for k in ks}}
+        algo = algorithmic_bytes(cn)
+        phases = phase_table(kernel_ms, algo)
         dom = max(phases, key=lambda p: phases[p]["ms"])
-        traffic, valu = None, None
+        # the dominant kernel's duration inside the timed region (HIP events on its dispatches) when it is the
+        # sketch kernel and events were on; otherwise its duration alone
+        dom_ms = sketch_ms / steps if (dom == "sketch+probe" and prof) else phases[dom]["ms"]
+        achieved = algo[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, valu, pmc_src = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(args.workload, {})
                 traffic = rec.get(dom)
+                pmc_src = rec.get("source")
                 # the sketch kernel is bounded by integer VALU issue: wavefront instructions per launch (PMC
-                # SQ_INSTS_VALU, same workload) against 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles
-                if dom == "sketch" and rec.get("sketch_valu_insts") and args.scale == 1.0:
-                    peak = 256 * 4 * 2.4e9 / 4
-                    rate = rec["sketch_valu_insts"] / (phases[dom]["ms"] * 1e-3)
-                    valu = {"wave_insts_per_launch": rec["sketch_valu_insts"], "achieved_insts_per_s": rate,
-                            "peak_insts_per_s": peak, "frac": rate / peak,
-                            "note": "VALU issue roofline at 2.4 GHz; the kernel's binding limit"}
+                # SQ_INSTS_VALU, same workload) against the issue rate of the whole chip
+                if dom == "sketch+probe" and rec.get("sketch_valu_insts") and args.scale == 1.0:
+                    valu = {"wave_insts_per_launch": rec["sketch_valu_insts"], "peak_insts_per_s": VALU_PEAK_WAVE_INSTS,
+                            "frac": rec["sketch_valu_insts"] / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS,
+                            "note": "VALU issue roofline at 2.4 GHz, the kernel's binding limit; instruction count "
+                                    "from the committed PMC pass, duration from this run"}
             except Exception:
                 traffic, valu = None, None
-        roofline = {"bound": "hbm", "kernel": "%s phase (%s)" % (dom, "+".join(PHASES[dom])),
-                    "achieved": phases[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": phases[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "ms_per_launch": phases[dom]["ms"], "algorithmic_bytes_per_launch": algo[dom], "valu": valu}
-        if dom == "sketch" and sketch_alone_ms > 0:
-            alone = sketch_alone_ms / steps
-            roofline["ms_per_launch_alone"] = alone
-            roofline["achieved_alone"] = algo[dom] / (alone * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "limited_by": "valu" if dom == "sketch+probe" else "latency",
+                    "kernel": "%s (%s)" % (dom, "+".join(k for k in PHASES[dom] if kernel_ms.get(k, 0.0) > 0)),
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic,
+                    "traffic_source": ("not measured in this run: %s" % pmc_src) if traffic is not None else None,
+                    "ms_per_launch": dom_ms, "algorithmic_bytes_per_launch": algo[dom],
+                    "algorithmic_bytes_definition": ALGO_DEF, "valu": valu}
+        if dom == "sketch+probe" and sketch_alone_ms > 0:
+            roofline["ms_per_launch_alone"] = sketch_alone_ms
+            roofline["achieved_alone"] = algo[dom] / (sketch_alone_ms * 1e-3) / 1e9
             if prof:
                 # the library alternates the sketch kernels of successive steps between two streams: launches
                 # overlap, each lasts longer than it would alone, and together they move this many bytes per second
                 roofline["launches_in_flight"] = sketch_ms / (elapsed_local * 1e3)
                 roofline["achieved_all_launches"] = algo[dom] * args.steps / elapsed_local / 1e9
             if valu:
-                valu["frac_alone"] = valu["wave_insts_per_launch"] / (alone * 1e-3) / valu["peak_insts_per_s"]
+                valu["frac_alone"] = valu["wave_insts_per_launch"] / (sketch_alone_ms * 1e-3) / VALU_PEAK_WAVE_INSTS
+        total_algo = sum(algo.values())
         out = {
             "metric": "read bases mapped/sec (sketch+probe+cluster)",
             "value": total_bases * args.steps / elapsed,
@@ -326,18 +408,47 @@ def main():
                        "minimizers_per_gpu": cn["n_minimizers"], "hits_per_gpu": cn["n_hits"],
                        "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],
                        "index_keys": int(len(si.keys)), "index_records": int(len(si.rec_prg)),
+                       "index_intervals": int(len(si.iv_start)),
                        "parallelism": "reads sharded over %d GPU(s), index replicated" % world,
                        "steps_in_flight": depth},
             "hits_per_s": total_hits * args.steps / elapsed,
             "roofline": roofline,
             "phases": phases,
-            "sort_passes_P": P,
-            "upload_and_encode_s": upload_s,
+            "whole_step": {"algorithmic_bytes": total_algo,
+                           "GBps": total_algo / (elapsed_local / steps) / 1e9,
+                           "frac_of_hbm_peak": total_algo / (elapsed_local / steps) / 1e9 / HBM_PEAK_GBS},
+            "upload_and_encode_s": wl.upload_s,
+            "end_to_end": {"note": "one batch from pageable host memory as ASCII: upload + encode + one step",
+                           "bases_per_s": cn["n_bases"] / (wl.upload_s + elapsed_local / steps)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(si, bases, offsets, prm, fraction)
+            progress("cpu baseline")
+            out["cpu_baseline"] = cpu_baseline(si, wl.bases, wl.offsets, prm, wl.fraction)
         else:
             out["cpu_baseline"] = None
+        names = []
+        if world == 1 and args.others != "none" and args.last_stage == 0:
+            names = ["nanopore_1k_linear", "nanopore_1k_families", "illumina_1k", "illumina_w1", "nanopore_20k",
+                     "illumina_20k_w1", "nanopore_200k"] if args.others == "default" else args.others.split(",")
+        for r in ring:
+            if r is not None:
+                r.close()
+        res.close()
+        wl.close()
+        others, t_others = {}, time.perf_counter()
+        for name in names:
+            if name == args.workload:
+                continue
+            if time.perf_counter() - t_others > args.others_budget:
+                others[name] = "skipped: the time budget of the other workloads was used up"
+                continue
+            progress("other workload %s" % name)
+            try:
+                others[name] = other_workload(api, synth, name, 1.0, depth, 0.5)
+            except Exception as e:      # a side measurement must not lose the headline line
+                others[name] = "failed: %r" % (e,)
+        if names:
+            out["other_workloads"] = others
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:

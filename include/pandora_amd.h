@@ -341,6 +341,15 @@ int pmap_pangraph_hits(const pmap_pangraph_t *pg, uint32_t *read_id, uint32_t *p
 /* The add_node call sequence: (prg_id, read_id, cluster size, is_forward of first hit). */
 int pmap_pangraph_calls(const pmap_pangraph_t *pg, uint32_t *prg_id, uint32_t *read_id, uint32_t *size,
                         uint8_t *is_forward);
+/* The cluster handed to every add_node call (add_clusters_to_pangraph,
+ * src/utils.cpp:338-352): call j of pmap_pangraph_calls owns entries
+ * [hit_off[j], hit_off[j+1]) of pos / rec (hit_off has n_add_node_calls + 1
+ * entries, pos / rec n_hits), in MinimizerHit::operator< order, i.e. as the
+ * std::set<MinimizerHitPtr, pComp> of that cluster iterates.  Every hit of a
+ * call has the call's read_id, prg_id and is_forward; rec is the index record
+ * (caller's numbering) that gives prg_path and kmer_node_id.  Any pointer may
+ * be NULL.  Not available with PMAP_PG_NO_HITS. */
+int pmap_pangraph_call_hits(const pmap_pangraph_t *pg, uint64_t *hit_off, uint32_t *pos, uint32_t *rec);
 /* With PMAP_PG_COVERAGE: the coverage every index record's kmer node has after
  * add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383), forward and
  * reverse hits, n_records entries each in the caller's record numbering. */

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pmap_pangraph_reads": (C.c_int, [C.c_void_p, u32p, u64p, u32p, u8p]),
     "pmap_pangraph_hits": (C.c_int, [C.c_void_p, u32p, u32p, u32p, u32p, u8p]),
     "pmap_pangraph_calls": (C.c_int, [C.c_void_p, u32p, u32p, u32p, u8p]),
+    "pmap_pangraph_call_hits": (C.c_int, [C.c_void_p, u64p, u32p, u32p]),
     "pmap_pangraph_coverage": (C.c_int, [C.c_void_p, u32p, u32p]),
     "pmap_pangraph_destroy": (None, [C.c_void_p]),
     "pmap_reads_update": (C.c_int, [C.c_void_p, C.c_char_p, u64p, C.c_uint32, C.c_uint32]),

@@ -361,6 +361,15 @@ class Pangraph:
         a["fwd"] = fwd
         return a
 
+    def call_hits(self):
+        """The cluster of every add_node call: (hit_off, pos, rec); call j owns [hit_off[j], hit_off[j+1])."""
+        i = self.info()
+        off = np.zeros(i["n_add_node_calls"] + 1, np.uint64)
+        pos = np.zeros(i["n_hits"], np.uint32)
+        rec = np.zeros(i["n_hits"], np.uint32)
+        _check(_lib.load().pmap_pangraph_call_hits(self._h, _p(off, u64p), _p(pos, u32p), _p(rec, u32p)))
+        return off, pos, rec
+
     def close(self):
         if self._h:
             _lib.load().pmap_pangraph_destroy(self._h)

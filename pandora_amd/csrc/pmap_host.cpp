@@ -264,10 +264,12 @@ struct PgRead {
 struct pmap_pangraph {
     std::map<uint32_t, uint32_t> node_covg;   // node id (= prg id) -> covg
     std::map<uint32_t, PgRead> reads;
-    HitBuf hits;
+    HitBuf hits;                      // in add_node call order, each call's cluster in pComp order
     std::vector<uint32_t> call_prg, call_read, call_size;
     std::vector<uint8_t> call_fwd;
-    bool hits_sorted = false;
+    bool keep_hits = true;
+    std::vector<uint64_t> by_path;    // hits in Read::hits order (indices into `hits`), built on demand
+    bool by_path_valid = false;
     pmap_coverage_t *cov = nullptr;   // device coverage counters (PMAP_PG_COVERAGE)
 };
 
@@ -289,16 +291,22 @@ static void pg_add_node(pmap_pangraph *pg, uint32_t prg, uint32_t read, uint32_t
 }
 
 static void pg_sort_hits(pmap_pangraph *pg) {
-    if (pg->hits_sorted) return;
-    // per (read, prg): pComp_path (src/minihits.cpp:77-93): path, forward first, position
-    std::sort(pg->hits.begin(), pg->hits.end(), [](const PgHit &a, const PgHit &b) {
+    if (pg->by_path_valid) return;
+    // per (read, prg): pComp_path (src/minihits.cpp:77-93): path, forward first, position.  The hits themselves
+    // stay in call order (pmap_pangraph_call_hits); this is an index into them.
+    pg->by_path.resize(pg->hits.size());
+    std::iota(pg->by_path.begin(), pg->by_path.end(), 0ull);
+    const PgHit *h = pg->hits.p;
+    std::sort(pg->by_path.begin(), pg->by_path.end(), [h](uint64_t x, uint64_t y) {
+        const PgHit &a = h[x], &b = h[y];
         if (a.read != b.read) return a.read < b.read;
         if (a.prg != b.prg) return a.prg < b.prg;
         if (a.rank != b.rank) return a.rank < b.rank;
         if (a.fwd != b.fwd) return a.fwd > b.fwd;
-        return a.pos < b.pos;
+        if (a.pos != b.pos) return a.pos < b.pos;
+        return x < y;
     });
-    pg->hits_sorted = true;
+    pg->by_path_valid = true;
 }
 
 // ---------------------------------------------------------------------------
@@ -506,7 +514,7 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, pmap_pangraph *pg,
                 pg->hits.push_unchecked(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
         }
     }
-    pg->hits_sorted = false;
+    pg->by_path_valid = false;
     if (cov) {
         // add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383) walks Node::reads, a multiset that
         // holds a read once per add_node call, and for each entry every hit of the read on that node: a
@@ -549,6 +557,7 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     const bool keep_hits = !(a->flags & PMAP_PG_NO_HITS);
 
     pmap_pangraph *pg = new pmap_pangraph();
+    pg->keep_hits = keep_hits;
     if ((a->flags & PMAP_PG_COVERAGE) && (rc = pmap_coverage_create(idx, &pg->cov))) {
         delete pg;
         return rc;
@@ -650,7 +659,7 @@ extern "C" int pmap_pangraph_hits(const pmap_pangraph_t *pgc, uint32_t *read_id,
     pmap_pangraph *pg = const_cast<pmap_pangraph *>(pgc);
     pg_sort_hits(pg);
     for (size_t i = 0; i < pg->hits.size(); ++i) {
-        const PgHit &h = pg->hits[i];
+        const PgHit &h = pg->hits[pg->by_path[i]];
         if (read_id) read_id[i] = h.read;
         if (prg_id) prg_id[i] = h.prg;
         if (pos) pos[i] = h.pos;
@@ -668,6 +677,27 @@ extern "C" int pmap_pangraph_calls(const pmap_pangraph_t *pg, uint32_t *prg_id, 
     if (read_id) memcpy(read_id, pg->call_read.data(), n * 4);
     if (size) memcpy(size, pg->call_size.data(), n * 4);
     if (is_forward) memcpy(is_forward, pg->call_fwd.data(), n);
+    return PMAP_OK;
+}
+
+// the cluster of every add_node call (src/utils.cpp:346-351): call j owns hits [hit_off[j], hit_off[j+1])
+extern "C" int pmap_pangraph_call_hits(const pmap_pangraph_t *pg, uint64_t *hit_off, uint32_t *pos, uint32_t *rec) {
+    if (!pg) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (!pg->keep_hits) return pmap_fail(PMAP_EINVAL, "the pangraph was built with PMAP_PG_NO_HITS");
+    const size_t n = pg->call_prg.size();
+    if (hit_off) {
+        uint64_t o = 0;
+        for (size_t j = 0; j < n; ++j) {
+            hit_off[j] = o;
+            o += pg->call_size[j];
+        }
+        hit_off[n] = o;
+        if (o != pg->hits.size()) return pmap_fail(PMAP_EINVAL, "hit lists and add_node calls out of step");
+    }
+    for (size_t i = 0; i < pg->hits.size(); ++i) {
+        if (pos) pos[i] = pg->hits[i].pos;
+        if (rec) rec[i] = pg->hits[i].rec;
+    }
     return PMAP_OK;
 }
 

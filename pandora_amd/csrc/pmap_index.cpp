@@ -232,7 +232,7 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
     uint32_t max_fbits = 24;
     if (const char *cap_env = getenv("PMAP_FILTER_MAX_BITS")) {      // tests: every filter mode with a small index
         const int v = atoi(cap_env);
-        if (v >= 6 && v <= 24) max_fbits = (uint32_t) v;
+        if (v >= 6 && v <= 30) max_fbits = (uint32_t) v;
     }
     uint32_t fbits = std::min<uint32_t>(log2cap + 3, max_fbits);
     if (idx->n_keys * 4 > (1ull << fbits)) fbits = 0;
@@ -544,7 +544,7 @@ extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out)
     if (h.version != CACHE_VERSION) return bad("written by another version");
     const uint32_t fb = h.filter_bits & 0xFFu;     // number of filter bits; PMAP_FILTER_TWO rides above it
     if (h.k < 1 || h.k > 31 || h.log2cap > 31 || h.n_slots != (1ull << h.log2cap) || h.n_recs >= 0xFFFFFFFFull ||
-        h.n_keys > h.n_recs || (h.filter_bits & ~(0xFFu | PMAP_FILTER_TWO)) || fb > 24 || (fb && fb < 6) ||
+        h.n_keys > h.n_recs || (h.filter_bits & ~(0xFFu | PMAP_FILTER_TWO)) || fb > 30 || (fb && fb < 6) ||
         (!fb && h.filter_bits) || h.n_filter_words != (fb ? (1ull << (fb - 5)) : 0))
         return bad("inconsistent header");
     // the file must be exactly as long as the header says, before anything is allocated from it

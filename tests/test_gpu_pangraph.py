@@ -70,6 +70,32 @@ def _check_pangraph(pg, res, covg):
     h = pg.hits()
     got = list(zip(h["read"].tolist(), h["prg"].tolist(), h["pos"].tolist(), h["rec"].tolist(), h["fwd"].tolist()))
     assert len(got) == len(exp_hits) and set(got) == exp_hits
+    # the cluster of every call, as add_clusters_to_pangraph hands it to add_node (src/utils.cpp:346-351):
+    # the call's slice of the oracle's sorted hits, in pComp order
+    off, cpos, crec = pg.call_hits()
+    assert len(off) == len(calls["prg"]) + 1 and off[0] == 0 and off[-1] == len(got)
+    np.testing.assert_array_equal(np.diff(off.astype(np.int64)), res["cl_size"][alive])
+    ob = res["cl_begin"][alive].astype(np.int64)
+    idx = np.concatenate([np.arange(b, b + s) for b, s in zip(ob, res["cl_size"][alive])]) if len(ob) else \
+        np.zeros(0, np.int64)
+    np.testing.assert_array_equal(cpos, res["hit_pos"][idx])
+    np.testing.assert_array_equal(crec, res["hit_rec"][idx])
+    # replay of the calls the way a binding does it (pangenome::Graph::add_node, src/pangenome/pangraph.cpp:
+    # 108-140): Read::add_hits must find every hit new, the orientation comes from the cluster's first hit
+    read_hits, node_covg, read_nodes = {}, {}, {}
+    for j in range(len(calls["prg"])):
+        p, r, f = int(calls["prg"][j]), int(calls["read"][j]), int(calls["fwd"][j])
+        have = read_hits.setdefault((r, p), set())
+        for i in range(int(off[j]), int(off[j + 1])):
+            hit = (int(cpos[i]), int(crec[i]), f)
+            assert hit not in have                       # src/pangenome/panread.cpp:25-27
+            have.add(hit)
+        node_covg[p] = node_covg.get(p, 0) + 1
+        lst = read_nodes.setdefault(r, [])
+        if not lst or lst[-1] != (p, f):
+            lst.append((p, f))
+    assert node_covg == exp_covg and read_nodes == exp_reads
+    assert {(r, p, pos, rec, f) for (r, p), hs in read_hits.items() for pos, rec, f in hs} == exp_hits
     return len(calls["prg"])
 
 
