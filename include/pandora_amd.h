@@ -10,9 +10,18 @@
  * Conventions: every function returns 0 on success and a non-zero PMAP_E* code
  * on failure; pmap_last_error() then returns a message (thread local).  All
  * pointers in the signatures are HOST pointers unless the name says `dev`.
- * Calls are blocking.  One process drives one GPU (select it with pmap_init),
- * from one thread at a time: the library keeps its streams and launch state in
- * process-wide variables and takes no locks.
+ * Calls are blocking.
+ *
+ * Devices and threads.  The library works through mapping contexts: one GPU,
+ * the streams the library drives it with, and the launch state of one host
+ * thread.  pmap_init(device) makes the first context on that GPU the calling
+ * thread's current one; every reads / result / coverage object belongs to the
+ * context that was current when it was created, and a call on an object switches
+ * the calling thread to the object's context.  Different threads may work in
+ * different contexts at the same time (that is how pmap_pangraph_from_read_file
+ * uses several GPUs, see pmap_init_devices); one context, and the objects that
+ * belong to it, must be used by one thread at a time.  An index may be shared
+ * by all contexts: it is uploaded once to every GPU it is used on.
  */
 #ifndef PANDORA_AMD_H
 #define PANDORA_AMD_H
@@ -38,9 +47,18 @@ typedef struct pmap_pangraph pmap_pangraph_t; /* host-side pangenome::Graph summ
 
 const char *pmap_last_error(void);
 
-/* Selects the GPU this process drives and creates the library's stream.
- * device < 0 keeps the current device. */
+/* Makes the first mapping context on GPU `device` (created if there is none
+ * yet) the calling thread's current one.  device < 0 keeps the thread's
+ * context, or makes one on the current HIP device. */
 int pmap_init(int device);
+
+/* The mapping contexts pmap_pangraph_from_read_file spreads the batches of a
+ * read file over: one per entry of `devices`, in this order; a GPU may be
+ * listed more than once (two contexts on one GPU overlap the upload of one
+ * batch with the kernels and the host work of another).  n = 0 goes back to
+ * the default, two contexts on the calling thread's GPU.  No counterpart in
+ * the reference, which is single-threaded: results do not depend on it. */
+int pmap_init_devices(const int *devices, int n);
 
 /* ---------------------------------------------------------------- index */
 
@@ -295,6 +313,14 @@ int pmap_filter_clusters(uint64_t n, const uint32_t *read_id, const uint32_t *fi
 int pmap_read_fastaq(const char *path, char **bases, uint64_t **offsets, uint32_t *n_reads, char **names,
                      uint64_t **name_offsets);
 void pmap_free(void *p);
+/* The same reads (no names) through the reader pmap_pangraph_from_read_file uses
+ * for plain files: the file is cut into pieces of about piece_bytes at line
+ * starts that look like a record header, every piece is parsed on its own, and
+ * pieces whose cut turns out to lie inside a record are parsed again together
+ * with the piece before.  The result never depends on piece_bytes.  (No
+ * counterpart in the reference, whose reader is sequential.) */
+int pmap_read_fastaq_pieces(const char *path, uint64_t piece_bytes, char **bases, uint64_t **offsets,
+                            uint32_t *n_reads);
 
 typedef struct {
     uint32_t w, k;

@@ -65,6 +65,7 @@ class PangraphInfo(C.Structure):
 SIGNATURES = {
     "pmap_last_error": (C.c_char_p, []),
     "pmap_init": (C.c_int, [C.c_int]),
+    "pmap_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "pmap_index_create": (C.c_int, [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]),
     "pmap_index_upload_now": (C.c_int, [C.c_void_p]),
     "pmap_index_load": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_void_p)]),
@@ -97,6 +98,7 @@ SIGNATURES = {
     "pmap_read_fastaq": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(u64p), u32p,
                                    C.POINTER(C.c_void_p), C.POINTER(u64p)]),
     "pmap_free": (None, [C.c_void_p]),
+    "pmap_read_fastaq_pieces": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(u64p), u32p]),
     "pmap_pangraph_from_read_file": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(MapArgs),
                                                C.POINTER(C.c_void_p), u32p]),
     "pmap_pangraph_info": (C.c_int, [C.c_void_p, C.POINTER(PangraphInfo)]),

@@ -34,6 +34,13 @@ def init(device=-1):
     _check(_lib.load().pmap_init(device))
 
 
+def init_devices(devices):
+    """The mapping contexts pangraph_from_read_file spreads its batches over: one per entry (a GPU may appear
+    more than once); [] = the default."""
+    arr = (C.c_int * max(len(devices), 1))(*devices)
+    _check(_lib.load().pmap_init_devices(arr, len(devices)))
+
+
 def fraction(e_rate, k):
     """fraction_kmers_required_for_cluster = 0.5 / exp(e_rate * k) (src/utils.cpp:394)."""
     return float(_lib.load().pmap_fraction(C.c_float(e_rate), k))
@@ -304,6 +311,20 @@ def read_fastaq(path):
         lib.pmap_free(C.cast(off, C.c_void_p))
         lib.pmap_free(C.cast(noff, C.c_void_p))
     return out
+
+
+def read_fastaq_pieces(path, piece_bytes):
+    """The reads of read_fastaq (without names) through the piece-wise parser of pangraph_from_read_file."""
+    lib = _lib.load()
+    bases = C.c_void_p()
+    off = u64p()
+    n = C.c_uint32()
+    _check(lib.pmap_read_fastaq_pieces(str(path).encode(), piece_bytes, C.byref(bases), C.byref(off), C.byref(n)))
+    try:
+        return [C.string_at(bases.value + off[i], off[i + 1] - off[i]).decode("latin-1") for i in range(n.value)]
+    finally:
+        lib.pmap_free(bases)
+        lib.pmap_free(C.cast(off, C.c_void_p))
 
 
 class Pangraph:

@@ -35,22 +35,37 @@
             return pmap_fail(PMAP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
-static hipStream_t g_stream = nullptr;   // coverage, clearing: an alias of g_tail
-// The map path runs on two sketch streams and a tail stream.  The sketch
-// kernels of successive batches alternate between the sketch streams (they do not depend on each
-// other): the second one fills the compute units as the first one drains, and the 15 us between two
-// kernels of one stream (end-of-kernel barrier, event, launch) are hidden behind the other stream.
-// Everything after the sketch kernel runs on g_tail behind an event: a string of short,
-// latency-bound kernels that now runs next to the sketch kernels of the following batches instead of
-// in front of them.  One step of the reference workload: 0.243 ms as the sum of its kernels, 0.245 ms
-// with one sketch stream, 0.230 ms with two.  (The streams of the library must not outnumber the
-// hardware queues of the process, 4 by default: with a fifth stream the same design took 0.267 ms.
-// Hence coverage and clearing share the tail stream.)
+// A mapping context: the streams one host thread drives one GPU with.  A process may hold several, on
+// different GPUs or on the same one (pmap_init_devices); every reads / result / coverage object belongs to
+// the context it was created in, and calls on it switch the calling thread to that context's GPU.
+//
+// The map path runs on two sketch streams and a tail stream.  The sketch kernels of successive batches
+// alternate between the sketch streams (they do not depend on each other): the second one fills the
+// compute units as the first one drains, and the 15 us between two kernels of one stream (end-of-kernel
+// barrier, event, launch) are hidden behind the other stream.  Everything after the sketch kernel runs on
+// `tail` behind an event: a string of short, latency-bound kernels that now runs next to the sketch
+// kernels of the following batches instead of in front of them.  One step of the reference workload:
+// 0.243 ms as the sum of its kernels, 0.245 ms with one sketch stream, 0.230 ms with two.  (The streams
+// of a process must not outnumber its hardware queues, 4 by default: with a fifth stream the same design
+// took 0.267 ms.  Hence coverage and clearing share the tail stream.)  Uploads and encodes run on their
+// own stream, so that a batch can be brought in while the kernels of the batch before it run.
 static const int N_SKETCH_STREAMS = 2;
-static hipStream_t g_sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, g_tail = nullptr;
-static unsigned g_sketch_turn = 0;
-static hipStream_t g_cur = nullptr;      // where KLAUNCH enqueues
-static bool g_ready = false;
+struct pmap_result;
+struct DevCtx {
+    int device = 0;
+    hipStream_t sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, tail = nullptr, upload = nullptr;
+    unsigned sketch_turn = 0;
+    // pmap_map_noalloc: this device's copy of the scratch array, a result object whose buffers are views
+    // of it and of the caller's outputs, pinned staging of the per-prg thresholds
+    unsigned char *scratch = nullptr;
+    pmap_result *na_view = nullptr;
+    uint32_t *thr_stage = nullptr;
+};
+static std::mutex g_ctx_mu;                       // guards the two lists below
+static std::vector<DevCtx *> g_all_ctx;           // every context ever made (they live until the process ends)
+static std::vector<DevCtx *> g_pool;              // pmap_init_devices: the contexts of pmap_pangraph_from_read_file
+static thread_local DevCtx *t_ctx = nullptr;      // the calling thread's current context
+static thread_local hipStream_t g_cur = nullptr;  // where KLAUNCH enqueues
 // Choice of the sketch kernel where the register-window kernel applies (k <= 15, default w), for
 // comparing the variants on a GPU: PMAP_SKETCH=lds keeps the LDS-window kernel, PMAP_SKETCH=np8
 // takes 8 instead of 16 positions per lane (PMAP_FLAG_SKETCH_* do the same per call).
@@ -86,41 +101,135 @@ static_assert(NA_OFF_GROUP % 256 == 0 && NA_OFF_TILECNT % 256 == 0 && NA_OFF_HBO
               "every part of the scratch array starts on a 256-byte boundary");
 static __device__ __align__(256) unsigned char pmap_scratch[64u << 20];
 
-struct pmap_result;
-static const int NA_MAX_DEVICES = 64;
-struct NoAllocDevice {
-    unsigned char *scratch = nullptr;     // this device's copy of pmap_scratch (hipGetSymbolAddress)
-    pmap_result *view = nullptr;          // a result whose buffers are views of the scratch array and of the caller's outputs
-    uint32_t *thr_stage = nullptr;        // pinned staging of the per-prg thresholds
-};
-static NoAllocDevice g_na[NA_MAX_DEVICES];
-static int noalloc_setup(int dev);
+static int noalloc_setup(DevCtx *ctx);
+
+// makes `ctx` the calling thread's context (and its GPU the thread's current device)
+static int bind(DevCtx *ctx) {
+    if (t_ctx != ctx) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        t_ctx = ctx;
+    }
+    return PMAP_OK;
+}
+
+// a new context on `device` (the calling thread's current device afterwards)
+static int new_context(int device, DevCtx **out) {
+    HIP_TRY(hipSetDevice(device));
+    DevCtx *ctx = new DevCtx();
+    ctx->device = device;
+    // all at the default priority: priorities made no difference to the timing, and with two processes
+    // on one GPU a low-priority sketch queue that the tail queue waits for was never scheduled
+    for (auto &sk : ctx->sketch) HIP_TRY(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
+    t_ctx = ctx;
+    if (int rc = noalloc_setup(ctx)) return rc;
+    std::lock_guard<std::mutex> l(g_ctx_mu);
+    g_all_ctx.push_back(ctx);
+    *out = ctx;
+    return PMAP_OK;
+}
+
+static int device_count(int *n) {
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess || *n == 0)
+        return pmap_fail(PMAP_EHIP, "no HIP device: libpandora_amd needs an AMD GPU (gfx950), there is no CPU fallback");
+    return PMAP_OK;
+}
 
 extern "C" int pmap_init(int device) {
     int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n == 0)
-        return pmap_fail(PMAP_EHIP, "no HIP device: libpandora_amd needs an AMD GPU (gfx950), there is no CPU fallback");
-    if (device >= 0) HIP_TRY(hipSetDevice(device));
-    if (!g_tail) {
-        // all at the default priority: priorities made no difference to the timing, and with two processes
-        // on one GPU a low-priority sketch queue that the tail queue waits for was never scheduled
-        for (auto &sk : g_sketch) HIP_TRY(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&g_tail, hipStreamNonBlocking));
-        g_stream = g_tail;
-    }
+    if (int rc = device_count(&n)) return rc;
     const char *sk = getenv("PMAP_SKETCH");
     g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
-    int cur = 0;
-    HIP_TRY(hipGetDevice(&cur));
-    if (int rc = noalloc_setup(cur)) return rc;
-    g_ready = true;
+    if (device < 0) {
+        if (t_ctx) return PMAP_OK;
+        HIP_TRY(hipGetDevice(&device));
+    }
+    if (device >= n || device >= pmap_index::MAX_DEVICES) return pmap_fail(PMAP_EINVAL, "no such device");
+    // the first context made on that device, or a new one
+    DevCtx *ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> l(g_ctx_mu);
+        for (DevCtx *c : g_all_ctx)
+            if (c->device == device) { ctx = c; break; }
+    }
+    if (ctx) return bind(ctx);
+    return new_context(device, &ctx);
+}
+
+extern "C" int pmap_init_devices(const int *devices, int n_devices) {
+    int n = 0;
+    if (int rc = device_count(&n)) return rc;
+    if (n_devices < 0 || (n_devices > 0 && !devices)) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (n_devices > 64) return pmap_fail(PMAP_ELIMIT, "more than 64 mapping contexts");
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= n || devices[i] >= pmap_index::MAX_DEVICES)
+            return pmap_fail(PMAP_EINVAL, "no such device");
+    DevCtx *before = t_ctx;
+    std::vector<DevCtx *> pool;
+    for (int i = 0; i < n_devices; ++i) {
+        // an entry reuses a context that exists on its device unless an earlier entry took it already
+        DevCtx *ctx = nullptr;
+        {
+            std::lock_guard<std::mutex> l(g_ctx_mu);
+            for (DevCtx *c : g_all_ctx)
+                if (c->device == devices[i] && std::find(pool.begin(), pool.end(), c) == pool.end()) { ctx = c; break; }
+        }
+        if (!ctx)
+            if (int rc = new_context(devices[i], &ctx)) return rc;
+        pool.push_back(ctx);
+    }
+    {
+        std::lock_guard<std::mutex> l(g_ctx_mu);
+        g_pool = pool;
+    }
+    // the calling thread stays where it was (or lands on the first context of the list)
+    t_ctx = nullptr;
+    if (before) return bind(before);
+    if (!pool.empty()) return bind(pool[0]);
     return PMAP_OK;
+}
+
+static int ensure_init();
+
+// The contexts pmap_pangraph_from_read_file works with: those of pmap_init_devices, or, by default, two on
+// the calling thread's GPU (made on first use and kept).
+int pmap_contexts_for_file(std::vector<void *> *out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    out->clear();
+    {
+        std::lock_guard<std::mutex> l(g_ctx_mu);
+        for (DevCtx *c : g_pool) out->push_back(c);
+    }
+    if (!out->empty()) return PMAP_OK;
+    DevCtx *mine = t_ctx, *second = nullptr;
+    {
+        std::lock_guard<std::mutex> l(g_ctx_mu);
+        for (DevCtx *c : g_all_ctx)
+            if (c->device == mine->device && c != mine) { second = c; break; }
+    }
+    if (!second) {
+        rc = new_context(mine->device, &second);
+        t_ctx = nullptr;
+        if (int rb = bind(mine)) return rb;
+        if (rc) return rc;
+    }
+    out->push_back(mine);
+    out->push_back(second);
+    return PMAP_OK;
+}
+
+int pmap_bind_context(void *ctx) {
+    if (!ctx) return pmap_fail(PMAP_EINVAL, "null argument");
+    t_ctx = nullptr;      // a new thread has no device set yet
+    return bind((DevCtx *) ctx);
 }
 
 void *pmap_pinned_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;     // any GPU may copy from it
     return p;
 }
 
@@ -129,7 +238,7 @@ void pmap_pinned_free(void *p) {
 }
 
 static int ensure_init() {
-    if (g_ready) return PMAP_OK;
+    if (t_ctx) return PMAP_OK;
     return pmap_init(-1);
 }
 
@@ -206,6 +315,7 @@ static SketchKind sketch_kind(uint32_t w, uint32_t k, uint32_t flags, uint32_t *
 // host objects
 
 struct pmap_reads {
+    DevCtx *ctx = nullptr;
     uint32_t n_reads = 0, first_read_id = 0;
     uint64_t n_bases = 0;
     uint32_t n_words = 0;      // packed words, each read padded to a multiple of 16 bases
@@ -225,6 +335,7 @@ static const char *kernel_names[PMAP_N_KERNELS] = {
     "sketch", "probe", "scatter", "sort_rank", "cluster_cut", "cluster_keep", "", "", "", "", "", "", "", "", "", ""};
 
 struct pmap_result {
+    DevCtx *ctx = nullptr;
     pmap_counts_t counts;
     uint32_t first_read_id = 0;
     uint32_t n_tiles = 0;
@@ -278,18 +389,22 @@ static int new_result(pmap_result **out);
 int pmap_index_upload(pmap_index *idx) {
     int rc = ensure_init();
     if (rc) return rc;
-    if (idx->d_slots) return PMAP_OK;
+    pmap_index::OnDevice &od = idx->dev[t_ctx->device];
+    std::lock_guard<std::mutex> l(idx->upload_mu);
+    if (od.slots) return PMAP_OK;
     size_t sb = idx->slots.size() * sizeof(PmapSlot), rb = (idx->recs.size() + 1) * sizeof(PmapRec);
-    HIP_TRY(hipMalloc((void **) &idx->d_slots, sb));
-    HIP_TRY(hipMalloc((void **) &idx->d_recs, rb));
-    HIP_TRY(hipMemcpy(idx->d_slots, idx->slots.data(), sb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **) &od.recs, rb));
     if (!idx->recs.empty())
-        HIP_TRY(hipMemcpy(idx->d_recs, idx->recs.data(), idx->recs.size() * sizeof(PmapRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(od.recs, idx->recs.data(), idx->recs.size() * sizeof(PmapRec), hipMemcpyHostToDevice));
     const size_t fb = idx->filter.size() * sizeof(uint32_t);
     if (fb) {
-        HIP_TRY(hipMalloc((void **) &idx->d_filter, fb));
-        HIP_TRY(hipMemcpy(idx->d_filter, idx->filter.data(), fb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **) &od.filter, fb));
+        HIP_TRY(hipMemcpy(od.filter, idx->filter.data(), fb, hipMemcpyHostToDevice));
     }
+    PmapSlot *slots = nullptr;
+    HIP_TRY(hipMalloc((void **) &slots, sb));
+    HIP_TRY(hipMemcpy(slots, idx->slots.data(), sb, hipMemcpyHostToDevice));
+    od.slots = slots;       // last: a set `slots` says the whole copy is there
     idx->device_bytes = sb + rb + fb;
     return PMAP_OK;
 }
@@ -300,22 +415,25 @@ extern "C" int pmap_index_upload_now(pmap_index_t *idx) {
 }
 
 void pmap_index_release_device(pmap_index *idx) {
-    if (idx->d_slots) (void) hipFree(idx->d_slots);
-    if (idx->d_recs) (void) hipFree(idx->d_recs);
-    if (idx->d_filter) (void) hipFree(idx->d_filter);
-    idx->d_filter = nullptr;
-    idx->d_slots = nullptr;
-    idx->d_recs = nullptr;
+    int before = -1;
+    (void) hipGetDevice(&before);
+    for (int d = 0; d < pmap_index::MAX_DEVICES; ++d) {
+        pmap_index::OnDevice &od = idx->dev[d];
+        if (!od.slots && !od.recs && !od.filter) continue;
+        (void) hipSetDevice(d);
+        if (od.slots) (void) hipFree(od.slots);
+        if (od.recs) (void) hipFree(od.recs);
+        if (od.filter) (void) hipFree(od.filter);
+        od = pmap_index::OnDevice();
+    }
+    if (before >= 0) (void) hipSetDevice(before);
 }
 
 // ---------------------------------------------------------------------------
 // reads
 
-// Uploads and encodes run on their own stream, so that a batch can be brought in while the kernels
-// of the batch before it run on the map stream.
-static hipStream_t g_upload = nullptr;
-
 static int launch_encode(pmap_reads *rd) {
+    hipStream_t g_upload = rd->ctx->upload;
     HIP_TRY(hipMemsetAsync(rd->rflag.p, 0, sizeof(uint32_t) * (rd->n_reads + 1), g_upload));
     if (rd->n_words) {
         hipLaunchKernelGGL(encode_kernel, dim3((rd->n_words + 255) / 256), dim3(256), 0, g_upload,
@@ -341,7 +459,8 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
         return pmap_fail(PMAP_EINVAL, "null argument");
     if ((uint64_t) first_read_id + n_reads > 0xFFFFFFFEull)
         return pmap_fail(PMAP_ELIMIT, "read ids exceed 32 bits (src/minihit.cpp:18-19)");
-    if (!g_upload) HIP_TRY(hipStreamCreateWithFlags(&g_upload, hipStreamNonBlocking));
+    if (int rcb = bind(rd->ctx)) return rcb;
+    hipStream_t g_upload = rd->ctx->upload;
     std::vector<uint32_t> &woff = rd->h_woff, &rlen = rd->h_rlen;
     std::vector<uint64_t> &boff = rd->h_boff;
     woff.assign(n_reads + 1, 0);
@@ -399,6 +518,7 @@ extern "C" int pmap_reads_create(const char *bases, const uint64_t *offsets, uin
     if (rc) return rc;
     if (!out) return pmap_fail(PMAP_EINVAL, "null argument");
     pmap_reads *rd = new pmap_reads();
+    rd->ctx = t_ctx;
     if ((rc = reads_fill(rd, bases, offsets, n_reads, first_read_id))) {
         pmap_reads_destroy(rd);
         return rc;
@@ -415,9 +535,9 @@ extern "C" int pmap_reads_update(pmap_reads_t *rd, const char *bases, const uint
 
 extern "C" int pmap_reads_repack(pmap_reads_t *rd) {
     if (!rd) return pmap_fail(PMAP_EINVAL, "null argument");
-    int rc = launch_encode(rd);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g_upload));
+    int rc = bind(rd->ctx);
+    if (rc || (rc = launch_encode(rd))) return rc;
+    HIP_TRY(hipStreamSynchronize(rd->ctx->upload));
     return PMAP_OK;
 }
 
@@ -431,6 +551,7 @@ extern "C" int pmap_reads_info(const pmap_reads_t *rd, uint32_t *n_reads, uint64
 
 extern "C" void pmap_reads_destroy(pmap_reads_t *rd) {
     if (!rd) return;
+    if (rd->ctx) (void) bind(rd->ctx);
     rd->ascii.release(); rd->boff.release(); rd->woff.release(); rd->rlen.release(); rd->rflag.release();
     rd->words.release(); rd->rmeta.release();
     delete rd;
@@ -458,7 +579,7 @@ struct KTimer {
     // events for the next launch: the group's first launch carries the start event, every launch the stop event
     void events(hipEvent_t *s, hipEvent_t *e);
 };
-static KTimer *g_kt = nullptr;
+static thread_local KTimer *g_kt = nullptr;
 
 #define KLAUNCH_B(kernel, grid, block, ...)                                                                 \
     do {                                                                                                    \
@@ -520,7 +641,11 @@ static int run_pipeline(pmap_result *res) {
     const bool fused = res->p_fused;
     const uint32_t last = res->p_last;
     KTimer kt{res, prm->profile >= 1, prm->profile == 2 ? 1u << KT_SKETCH : ~0u};
-    hipStream_t sketch_stream = g_sketch[g_sketch_turn++ % N_SKETCH_STREAMS];
+    DevCtx *ctx = res->ctx;
+    if ((rc = bind(ctx))) return rc;
+    const pmap_index::OnDevice &od = idx->dev[ctx->device];
+    hipStream_t g_tail = ctx->tail;
+    hipStream_t sketch_stream = ctx->sketch[ctx->sketch_turn++ % N_SKETCH_STREAMS];
     g_cur = sketch_stream;
     const uint32_t k = prm->k, w = prm->w;
     const bool k32 = k <= 15;
@@ -557,8 +682,8 @@ static int run_pipeline(pmap_result *res) {
     if (n_tiles) {
         kt.begin(KT_SKETCH);
 #define SKETCH_ARGS                                                                                                   \
-    rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, idx->d_slots, idx->log2cap,            \
-        idx->d_filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>(), \
+    rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, od.slots, idx->log2cap,                 \
+        od.filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>(), \
         aux
 #define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
     KLAUNCH(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
@@ -621,8 +746,8 @@ static int run_pipeline(pmap_result *res) {
         const bool emit = last >= PMAP_STAGE_HITS;
         if (!fused && emit) {
             kt.begin(KT_PROBE);
-            KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(), n_tiles, idx->d_slots,
-                    idx->log2cap, idx->d_filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>(),
+            KLAUNCH(probe_wave_kernel, dim3((n_tiles + 3) / 4), res->mkmer.as<uint64_t>(), n_tiles, od.slots,
+                    idx->log2cap, od.filter, idx->filter_bits, res->ents.as<uint4>(), res->tile_cnt.as<uint4>(),
                     res->tile_stride);
             kt.end(KT_PROBE);
         }
@@ -632,7 +757,7 @@ static int run_pipeline(pmap_result *res) {
                 res->group_sum.as<uint4>());
         KLAUNCH(scatter_group_kernel, dim3((n_waves + 3) / 4), res->tile_cnt.as<uint4>(), n_tiles, res->tile_stride,
                 res->ents.as<uint4>(),
-                idx->d_recs, res->hit_cap, emit ? 1u : 0u, dc, res->group_sum.as<uint4>(), rd->n_reads + 1,
+                od.recs, res->hit_cap, emit ? 1u : 0u, dc, res->group_sum.as<uint4>(), rd->n_reads + 1,
                 res->hbounds.as<uint32_t>(),
                 res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),
                 res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>());
@@ -702,14 +827,18 @@ extern "C" int pmap_map_wait(pmap_result_t *res);
 
 extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, const pmap_params_t *prm,
                               pmap_result_t **result) {
-    int rc = ensure_init();
-    if (rc) return rc;
+    int rc;
     if (!idx || !rd || !prm || !result) return pmap_fail(PMAP_EINVAL, "null argument");
     if (prm->k != idx->k) return pmap_fail(PMAP_EINVAL, "k differs from the k the index was built with");
     if (prm->w < 1 || prm->w > (uint32_t) SK_MAX_W)
         return pmap_fail(PMAP_EINVAL, "w must be in [1,64]");
-    if (!idx->d_slots && (rc = pmap_index_upload(const_cast<pmap_index *>(idx)))) return rc;
+    // the batch's context decides where the call runs
+    DevCtx *ctx = rd->ctx;
+    if ((rc = bind(ctx))) return rc;
+    if (!idx->dev[ctx->device].slots && (rc = pmap_index_upload(const_cast<pmap_index *>(idx)))) return rc;
     pmap_result *res = *result;
+    if (res && res->ctx != ctx)
+        return pmap_fail(PMAP_EINVAL, "the result object belongs to another mapping context than the reads");
     if (!res) {
         if ((rc = new_result(result))) {
             pmap_result_destroy(*result);
@@ -718,6 +847,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
         }
         res = *result;
     }
+    hipStream_t g_tail = ctx->tail;
     if (res->pending && (rc = pmap_map_wait(res))) return rc;   // the buffers are about to be reused
     const uint32_t last = prm->last_stage ? prm->last_stage : PMAP_STAGE_CLUSTER;
     const bool fused = !(prm->flags & PMAP_FLAG_UNFUSED) && last >= PMAP_STAGE_HITS;
@@ -780,6 +910,7 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
     if (!res->pending) return PMAP_OK;
     res->pending = false;
     int rc;
+    if ((rc = bind(res->ctx))) return rc;
     const uint32_t last = res->p_last;
     pmap_counts_t &cn = res->counts;
     unsigned long long n_mini = 0, n_hits = 0;
@@ -846,8 +977,9 @@ extern "C" int pmap_map(const pmap_index_t *idx, const pmap_reads_t *rd, const p
 // ---------------------------------------------------------------------------
 // pmap_map without allocations
 
-static int new_result(pmap_result **out) {
+static int new_result(pmap_result **out) {     // in the calling thread's context
     pmap_result *res = new pmap_result();
+    res->ctx = t_ctx;
     memset(&res->counts, 0, sizeof(res->counts));
     memset(res->kernel_ms, 0, sizeof(res->kernel_ms));
     *out = res;
@@ -859,12 +991,11 @@ static int new_result(pmap_result **out) {
     return PMAP_OK;
 }
 
-// Once per device, with that device current (pmap_init): the address of this device's copy of the
-// scratch array, and everything else pmap_map_noalloc would otherwise have to create per call.
-static int noalloc_setup(int dev) {
-    if (dev < 0 || dev >= NA_MAX_DEVICES) return pmap_fail(PMAP_ELIMIT, "device number beyond the library's table");
-    NoAllocDevice &na = g_na[dev];
-    if (na.scratch) return PMAP_OK;
+// Once per context, with its device current (pmap_init / pmap_init_devices): the address of this device's
+// copy of the scratch array, and everything else pmap_map_noalloc would otherwise have to create per call.
+// Contexts on one device get the same address: they share that device's one array.
+static int noalloc_setup(DevCtx *ctx) {
+    if (ctx->scratch) return PMAP_OK;
     void *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(pmap_scratch));
     if (e != hipSuccess || !ptr)
@@ -872,11 +1003,11 @@ static int noalloc_setup(int dev) {
     size_t bytes = 0;
     HIP_TRY(hipGetSymbolSize(&bytes, HIP_SYMBOL(pmap_scratch)));
     if (bytes < NA_SCRATCH_BYTES) return pmap_fail(PMAP_EHIP, "the scratch array is smaller than its layout");
-    HIP_TRY(hipHostMalloc((void **) &na.thr_stage, 4 * (NA_MAX_PRG + 64), hipHostMallocDefault));
-    int rc = new_result(&na.view);
+    HIP_TRY(hipHostMalloc((void **) &ctx->thr_stage, 4 * (NA_MAX_PRG + 64), hipHostMallocDefault));
+    int rc = new_result(&ctx->na_view);
     if (rc) return rc;
     unsigned char *base = (unsigned char *) ptr;
-    pmap_result *v = na.view;
+    pmap_result *v = ctx->na_view;
     v->state.view(base + NA_OFF_STATE, NA_OFF_GROUP - NA_OFF_STATE);
     v->group_sum.view(base + NA_OFF_GROUP, NA_OFF_TILECNT - NA_OFF_GROUP);
     v->tile_cnt.view(base + NA_OFF_TILECNT, NA_OFF_HBOUNDS - NA_OFF_TILECNT);
@@ -890,25 +1021,26 @@ static int noalloc_setup(int dev) {
     v->mkmer.view(nullptr, 0);
     v->bsum.view(nullptr, 0);
     v->scratch_total.view(nullptr, 0);
-    na.scratch = base;
+    ctx->scratch = base;
     return PMAP_OK;
 }
 
 extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd, const pmap_params_t *prm,
                                 const pmap_dev_out_t *out, pmap_counts_t *counts) {
     if (!idx || !rd || !prm || !out || !counts) return pmap_fail(PMAP_EINVAL, "null argument");
-    if (!g_ready) return pmap_fail(PMAP_EINVAL, "call pmap_init first: pmap_map_noalloc sets nothing up by itself");
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= NA_MAX_DEVICES || !g_na[dev].scratch)
-        return pmap_fail(PMAP_EINVAL, "pmap_init has not been called for the current device");
-    NoAllocDevice &na = g_na[dev];
-    pmap_result *res = na.view;
+    if (!t_ctx) return pmap_fail(PMAP_EINVAL, "call pmap_init first: pmap_map_noalloc sets nothing up by itself");
+    DevCtx *ctx = rd->ctx;
+    if (int rcb = bind(ctx)) return rcb;
+    if (!ctx->scratch || !ctx->na_view)
+        return pmap_fail(PMAP_EINVAL, "the reads' mapping context has no scratch array");
+    DevCtx &na = *ctx;
+    pmap_result *res = ctx->na_view;
+    hipStream_t g_tail = ctx->tail;
     if (prm->k != idx->k) return pmap_fail(PMAP_EINVAL, "k differs from the k the index was built with");
     if (prm->w < 1 || prm->w > (uint32_t) SK_MAX_W) return pmap_fail(PMAP_EINVAL, "w must be in [1,64]");
     if ((prm->flags & PMAP_FLAG_UNFUSED) || (prm->last_stage && prm->last_stage != PMAP_STAGE_CLUSTER))
         return pmap_fail(PMAP_EINVAL, "pmap_map_noalloc runs the whole path in its default mode only");
-    if (!idx->d_slots)
+    if (!idx->dev[ctx->device].slots)
         return pmap_fail(PMAP_EINVAL, "the index is not on the device: call pmap_index_upload_now first (this entry point does not allocate)");
     if (!out->hit_read || !out->hit_key || !out->hit_pos || !out->hit_rank || !out->hit_rec || !out->cluster_rows)
         return pmap_fail(PMAP_EINVAL, "null output buffer");
@@ -987,6 +1119,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
 // every accessor of a result first waits for a run that is still in flight
 static int settled(const pmap_result_t *res) {
     if (!res) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc = bind(res->ctx)) return rc;      // the copies that follow run on the result's GPU
     return res->pending ? pmap_map_wait(const_cast<pmap_result_t *>(res)) : PMAP_OK;
 }
 
@@ -1037,7 +1170,7 @@ extern "C" int pmap_result_minimizers(const pmap_result_t *cres, uint64_t *kmer,
         (rc = ord.ensure(sizeof(uint32_t) * n)) || (rc = ops.ensure(sizeof(uint32_t) * n)) ||
         (rc = res->scratch_total.ensure(sizeof(unsigned long long))))
         return done(rc);
-    g_cur = g_tail;
+    g_cur = res->ctx->tail;
     hipLaunchKernelGGL(tile_field_kernel, dim3((res->n_tiles + 255) / 256), dim3(256), 0, g_cur,
                        res->tile_cnt.as<uint4>(), res->n_tiles, 0u, nmini.as<uint32_t>());
     if ((rc = device_scan<false>(res, nmini.as<uint32_t>(), moff.as<uint32_t>(), res->n_tiles,
@@ -1116,6 +1249,7 @@ extern "C" int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, u
 // coverage
 
 struct pmap_coverage {
+    DevCtx *ctx = nullptr;
     uint32_t n_recs = 0;
     DevBuf covg, weight;
 };
@@ -1126,6 +1260,8 @@ extern "C" int pmap_coverage_create(const pmap_index_t *idx, pmap_coverage_t **o
     if (!idx || !out) return pmap_fail(PMAP_EINVAL, "null argument");
     if (idx->n_recs >= 0x7FFFFFFFull) return pmap_fail(PMAP_ELIMIT, "too many records for 32-bit record indices");
     pmap_coverage *cov = new pmap_coverage();
+    cov->ctx = t_ctx;
+    hipStream_t g_stream = t_ctx->tail;
     cov->n_recs = (uint32_t) idx->n_recs;
     const size_t bytes = sizeof(uint32_t) * 2 * ((size_t) cov->n_recs + 1);
     if ((rc = cov->covg.ensure(bytes))) {
@@ -1146,6 +1282,9 @@ extern "C" int pmap_coverage_add(pmap_coverage_t *cov, const pmap_result_t *res,
     if (!weight) return pmap_fail(PMAP_EINVAL, "null argument");
     if (res->p_idx == nullptr || res->p_idx->n_recs != cov->n_recs)
         return pmap_fail(PMAP_EINVAL, "the result was mapped against another index than the coverage belongs to");
+    if (res->ctx != cov->ctx && res->ctx->device != cov->ctx->device)
+        return pmap_fail(PMAP_EINVAL, "the result and the coverage counters live on different GPUs");
+    hipStream_t g_stream = res->ctx->tail;
     int rc;
     if ((rc = cov->weight.ensure(sizeof(uint32_t) * n))) return rc;
     // blocking copy: the caller's array may change as soon as this call returns
@@ -1160,7 +1299,8 @@ extern "C" int pmap_coverage_add(pmap_coverage_t *cov, const pmap_result_t *res,
 
 extern "C" int pmap_coverage_fetch(const pmap_coverage_t *cov, uint32_t *forward, uint32_t *reverse) {
     if (!cov) return pmap_fail(PMAP_EINVAL, "null argument");
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (int rc = bind(cov->ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());     // adds may have come from results of several contexts on this GPU
     const size_t b = sizeof(uint32_t) * cov->n_recs;
     if (forward && b) HIP_TRY(hipMemcpy(forward, cov->covg.p, b, hipMemcpyDeviceToHost));
     if (reverse && b) HIP_TRY(hipMemcpy(reverse, cov->covg.as<uint32_t>() + cov->n_recs, b, hipMemcpyDeviceToHost));
@@ -1169,6 +1309,7 @@ extern "C" int pmap_coverage_fetch(const pmap_coverage_t *cov, uint32_t *forward
 
 extern "C" void pmap_coverage_destroy(pmap_coverage_t *cov) {
     if (!cov) return;
+    if (cov->ctx) (void) bind(cov->ctx);
     cov->covg.release();
     cov->weight.release();
     delete cov;
@@ -1176,6 +1317,7 @@ extern "C" void pmap_coverage_destroy(pmap_coverage_t *cov) {
 
 extern "C" void pmap_result_destroy(pmap_result_t *res) {
     if (!res) return;
+    if (res->ctx) (void) bind(res->ctx);
     if (res->pending) (void) hipEventSynchronize(res->done);
     for (DevBuf *b : res->all()) b->release();
     if (res->events) {

@@ -3,7 +3,10 @@
 // (src/minihits.cpp:95-109, src/utils.cpp:251-288), the add_node sequence
 // (src/utils.cpp:338-352, src/pangenome/pangraph.cpp:43-140) and the read loop of
 // pangraph_from_read_file (src/utils.cpp:379-455).
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -134,18 +137,67 @@ struct LineStream {
             }
         }
     }
+    // a stream has no seams: see MemLines
+    bool at_limit() const { return false; }
+    bool quality_line_beyond_piece() const { return false; }
 };
 
+// The same over a piece [begin, piece_end) of a file held in memory (a mapped plain file), for parsing the
+// pieces of one file on several threads.  A piece that is not the file's last ends at a seam: the start of
+// a line that begins with '>' or '@'.  The piece's parser reads that one line too (`limit` is its end),
+// because whether the record before the seam is complete shows only there, and then stops.
+struct MemLines {
+    const char *p = nullptr, *piece_end = nullptr, *limit = nullptr;
+    bool last = true;        // the piece runs to the end of the file: end-of-file semantics apply at `limit`
+    bool eofbit = false;
+    bool at_eof() {
+        if (eofbit) return true;
+        if (p < limit) return false;
+        if (last) eofbit = true;
+        return last;
+    }
+    bool getline(const char **line, size_t *len) {
+        *line = p;
+        *len = 0;
+        if (eofbit || p >= limit) {
+            eofbit = true;
+            return false;
+        }
+        const char *nl = (const char *) memchr(p, '\n', (size_t) (limit - p));
+        if (nl) {
+            *line = p;
+            *len = (size_t) (nl - p);
+            p = nl + 1;
+            return true;
+        }
+        *line = p;
+        *len = (size_t) (limit - p);
+        p = limit;
+        // the seam line of a piece may be the file's last line and lack its newline: what the end of the
+        // file does to the reader is the last piece's business
+        if (!last) return true;
+        eofbit = true;
+        return false;
+    }
+    bool at_limit() const { return !last && p >= limit; }
+    // after a '+' line: the quality line it announces would be the seam line or lie beyond it, so the
+    // seam is not where a record starts
+    bool quality_line_beyond_piece() const { return !last && p >= piece_end; }
+};
+
+enum { NEXT_RECORD = 0, NEXT_AT_SEAM = 1, NEXT_BAD_SEAM = 2, NEXT_NO_MEMORY = 3 };
+
+// FastaqHandler::get_next (src/fastaq_handler.cpp:43-71) over either source
+template <typename Src>
 struct FastaqReader {
-    LineStream in;
+    Src in;
     // the last line read: only its first character and its emptiness matter to get_next
     bool line_empty = true;
     char line_first = 0;
     std::string pending_name;     // the header line that ended the record before
     std::string name, read;
-    bool open(const char *path) { return in.open(path); }
     bool eof() { return in.at_eof(); }
-    void get_next() {   // src/fastaq_handler.cpp:43-71
+    int get_next() {
         if (!line_empty && (line_first == '>' || line_first == '@')) {
             name = pending_name;
             read.clear();
@@ -153,18 +205,20 @@ struct FastaqReader {
         const char *l;
         size_t n;
         for (;;) {
+            if (in.at_limit()) return NEXT_AT_SEAM;
             const bool good = in.getline(&l, &n);
             line_empty = n == 0;
             line_first = n ? l[0] : 0;
             if (!line_empty && (line_first == '>' || line_first == '@')) pending_name.assign(l + 1, n - 1);
-            if (!good) return;
+            if (!good) return NEXT_RECORD;
             if (!line_empty && line_first == '+') {
+                if (in.quality_line_beyond_piece()) return NEXT_BAD_SEAM;
                 in.getline(&l, &n);   // quality line
                 line_empty = n == 0;
                 line_first = n ? l[0] : 0;
                 if (!line_empty && (line_first == '>' || line_first == '@')) pending_name.assign(l + 1, n - 1);
             } else if (line_empty || line_first == '>' || line_first == '@') {
-                if (!read.empty() || line_empty) return;
+                if (!read.empty() || line_empty) return NEXT_RECORD;
                 name = pending_name;
                 read.clear();
             } else {
@@ -178,8 +232,8 @@ struct FastaqReader {
 
 extern "C" int pmap_read_fastaq(const char *path, char **bases, uint64_t **offsets, uint32_t *n_reads,
                                 char **names, uint64_t **name_offsets) {
-    FastaqReader fh;
-    if (!fh.open(path))
+    FastaqReader<LineStream> fh;
+    if (!fh.in.open(path))
         return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + path);   // src/fastaq_handler.cpp:18-21
     std::string all, allnames;
     std::vector<uint64_t> off{0}, noff{0};
@@ -214,6 +268,14 @@ extern "C" int pmap_read_fastaq(const char *path, char **bases, uint64_t **offse
 }
 
 extern "C" void pmap_free(void *p) { free(p); }
+
+static int read_fastaq_pieces(const char *path, uint64_t piece_bytes, char **bases, uint64_t **offsets, uint32_t *n_reads);
+
+extern "C" int pmap_read_fastaq_pieces(const char *path, uint64_t piece_bytes, char **bases, uint64_t **offsets,
+                                       uint32_t *n_reads) {
+    if (!path || piece_bytes == 0) return pmap_fail(PMAP_EINVAL, "null argument");
+    return read_fastaq_pieces(path, piece_bytes, bases, offsets, n_reads);
+}
 
 // ---------------------------------------------------------------------------
 // pangenome::Graph summary
@@ -270,7 +332,8 @@ struct pmap_pangraph {
     bool keep_hits = true;
     std::vector<uint64_t> by_path;    // hits in Read::hits order (indices into `hits`), built on demand
     bool by_path_valid = false;
-    pmap_coverage_t *cov = nullptr;   // device coverage counters (PMAP_PG_COVERAGE)
+    bool has_cov = false;             // PMAP_PG_COVERAGE: kmer node coverage, summed over the mapping contexts
+    std::vector<uint32_t> cov_fwd, cov_rev;
 };
 
 // pangenome::Graph::add_node (src/pangenome/pangraph.cpp:126-140) with get_node (:59-76) and
@@ -310,98 +373,79 @@ static void pg_sort_hits(pmap_pangraph *pg) {
 }
 
 // ---------------------------------------------------------------------------
-// pangraph_from_read_file as a three-stage pipeline: a reader thread parses the file into batches
-// (pinned host memory), the calling thread uploads batch i+1 and enqueues its kernels while the GPU
-// maps batch i, then finishes batch i-1 on the host (filter_clusters, add_node, coverage).
+// pangraph_from_read_file as a pipeline of threads:
+//   parse     plain file: the file is mapped into memory and cut into pieces at seams (line starts that
+//             look like a record header); several threads run the FastaqHandler state machine over one
+//             piece each, check every read for letters outside ACGT and copy the reads into a pinned
+//             buffer - a piece becomes one device batch.  gzip file: one thread does the same over the
+//             inflated stream.
+//   sequence  one thread takes the pieces in file order, checks that every seam really was a record
+//             boundary (else the two pieces are parsed again as one), and applies the read loop's rules
+//             (read ids, coverage stop, 10M-read stop, Illumina k-mer count; src/utils.cpp:397-440).
+//   map       one thread per mapping context (pmap_init_devices; by default two on the caller's GPU):
+//             upload, kernels, results back, filter_clusters, coverage - whole batches, in any order.
+//   retire    the calling thread performs the add_node calls batch by batch in file order.
 
 namespace {
 
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Batch {
-    char *data = nullptr;          // pinned
+    char *data = nullptr;          // pinned (plain memory when `pinned` is off: parsing without a GPU)
+    bool pinned = true;
     size_t size = 0, cap = 0;
     std::vector<uint64_t> offsets{0};
+    std::vector<uint8_t> sketchable;      // per read: long enough for one window and only ACGT letters
     uint32_t first_id = 0;
+    uint64_t seq = 0;
     pmap_params_t prm;
-    void reset(uint32_t first) {
+    // a piece of a mapped file
+    const char *piece_begin = nullptr, *piece_end = nullptr;
+    bool piece_last = false;
+    int exit_code = NEXT_RECORD;
+    void reset() {
         size = 0;
         offsets.assign(1, 0);
-        first_id = first;
+        sketchable.clear();
+        exit_code = NEXT_RECORD;
     }
     bool reserve(size_t want) {
         if (want <= cap) return true;
         size_t ncap = std::max(want, cap + cap / 2);
-        char *p = (char *) pmap_pinned_alloc(ncap);
-        if (!p) return false;
-        if (size) memcpy(p, data, size);
-        if (data) pmap_pinned_free(data);
-        data = p;
+        char *q = (char *) (pinned ? pmap_pinned_alloc(ncap) : malloc(ncap));
+        if (!q) return false;
+        if (size) memcpy(q, data, size);
+        release();
+        data = q;
         cap = ncap;
         return true;
     }
-    void append(const std::string &seq) {
-        memcpy(data + size, seq.data(), seq.size());
-        size += seq.size();
+    void release() {
+        if (data && pinned) pmap_pinned_free(data);
+        else if (data) free(data);
+        data = nullptr;
+        cap = 0;
+    }
+    bool append(const std::string &seq_, bool sk) {      // false: out of memory
+        if (size + seq_.size() > cap && !reserve(size + seq_.size() + 64)) return false;
+        memcpy(data + size, seq_.data(), seq_.size());
+        size += seq_.size();
         offsets.push_back(size);
+        sketchable.push_back(sk);
+        return true;
     }
-};
-
-// bounded hand-over of batches between the reader thread and the mapping thread
-struct BatchQueue {
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<Batch *> ready, free_list;
-    bool done = false;      // the reader has pushed its last batch
-    bool abort = false;     // the consumer gave up: the reader must stop
-    double reader_waited = 0, mapper_waited = 0;    // seconds each side spent waiting for the other (PMAP_TRACE_PIPELINE)
-    static double now() {
-        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    size_t n_reads() const { return offsets.size() - 1; }
+    void truncate(size_t n) {
+        offsets.resize(n + 1);
+        sketchable.resize(n);
+        size = offsets[n];
     }
-    Batch *get_free() {
-        std::unique_lock<std::mutex> l(m);
-        const double t0 = now();
-        cv.wait(l, [&] { return abort || !free_list.empty(); });
-        reader_waited += now() - t0;
-        if (abort) return nullptr;
-        Batch *b = free_list.front();
-        free_list.pop_front();
-        return b;
-    }
-    void put_free(Batch *b) {
-        { std::lock_guard<std::mutex> l(m); free_list.push_back(b); }
-        cv.notify_all();
-    }
-    void put_ready(Batch *b) {
-        { std::lock_guard<std::mutex> l(m); ready.push_back(b); }
-        cv.notify_all();
-    }
-    Batch *get_ready() {    // nullptr: no more batches
-        std::unique_lock<std::mutex> l(m);
-        const double t0 = now();
-        cv.wait(l, [&] { return done || !ready.empty(); });
-        mapper_waited += now() - t0;
-        if (ready.empty()) return nullptr;
-        Batch *b = ready.front();
-        ready.pop_front();
-        return b;
-    }
-    void finish() {
-        { std::lock_guard<std::mutex> l(m); done = true; }
-        cv.notify_all();
-    }
-    void stop() {
-        { std::lock_guard<std::mutex> l(m); abort = true; }
-        cv.notify_all();
-    }
-};
-
-struct ReaderResult {
-    uint64_t covg = 0;
-    int rc = PMAP_OK;
-    std::string error;
 };
 
 // true iff every letter is one that nt4 (src/inthash.cpp:42-63) maps below 4: A, C, G, T in either case or
-// a raw code 0..3.  This is the reader's hot loop: 16 letters per step where SSE2 is there.
+// a raw code 0..3.  This is the parsers' hot loop: 16 letters per step where SSE2 is there.
 bool all_acgt(const unsigned char *p, size_t n) {
     size_t i = 0;
     bool bad = false;
@@ -426,64 +470,398 @@ bool all_acgt(const unsigned char *p, size_t n) {
     return !bad;
 }
 
-// The read loop of pangraph_from_read_file (src/utils.cpp:397-440) up to the point where a read is
-// handed to the sketch: ids, coverage stop, 10M-read stop, Illumina expected k-mer count.
-void reader_thread(FastaqReader *fh, const pmap_map_args_t *a, pmap_params_t prm, uint64_t batch_bases,
-                   BatchQueue *q, ReaderResult *out) {
+// The read loop of pangraph_from_read_file (src/utils.cpp:397-440) up to the point where a read is handed
+// to the sketch: ids, coverage stop, 10M-read stop, Illumina expected k-mer count.
+struct ReadLoop {
+    const pmap_map_args_t *a;
+    pmap_params_t prm;
     uint64_t covg = 0;
     uint32_t id = 0;
-    Batch *b = q->get_free();
-    if (b) b->reset(0);
-    auto flush = [&]() -> bool {      // hands the batch over and takes an empty one
-        b->prm = prm;
-        q->put_ready(b);
-        b = q->get_free();
-        if (!b) return false;
-        b->reset(id);
-        return true;
-    };
-    while (b && !fh->eof()) {
-        fh->get_next();
-        const std::string &seq = fh->read;
-        // Seq::initialize -> the sketch is non-empty iff the read has a full window and only ACGT letters
-        const bool sketched = seq.size() + 1 >= (uint64_t) a->w + a->k &&
-                              all_acgt((const unsigned char *) seq.data(), seq.size());
+    bool stopped = false;
+    // false: the loop ends in front of this read.  true: the read takes the next id and travels in its batch
+    // (a read without a sketch consumes an id too, :409-412, and yields nothing); `stopped` may be set behind it.
+    bool take(size_t len, bool sketched) {
         if (sketched) {
-            covg += seq.size();                                         // :404
-            if (covg / a->genome_size > a->max_covg) break;             // :405-408
-            if (a->illumina && prm.expected_kmers == std::numeric_limits<uint32_t>::max()) {
-                // the threshold changes from here on: reads before this one had no sketch, so no hits
-                prm.expected_kmers = (uint32_t) (seq.size() * 2 / a->w);    // :413-416
+            covg += len;                                                // :404
+            if (covg / a->genome_size > a->max_covg) {                  // :405-408
+                stopped = true;
+                return false;
+            }
+            // the threshold changes from here on: reads before this one had no sketch, so no hits
+            if (a->illumina && prm.expected_kmers == std::numeric_limits<uint32_t>::max())
+                prm.expected_kmers = (uint32_t) (len * 2 / a->w);       // :413-416
+        }
+        id++;
+        if (sketched && id > 10000000) stopped = true;                  // :420-423
+        return true;
+    }
+};
+
+struct Outcome {           // what one mapped batch contributes to the pangraph
+    std::vector<uint32_t> prg, read, size;
+    std::vector<uint8_t> fwd;
+    std::vector<PgHit> hits;        // call order, each call's cluster in pComp order
+};
+
+struct Pipeline {
+    const pmap_index_t *idx = nullptr;
+    const pmap_map_args_t *a = nullptr;
+    bool keep_hits = true, want_cov = false;
+    uint64_t piece_bytes = 0, batch_bases = 0;
+
+    std::mutex m;
+    std::condition_variable cv;
+    bool abort = false;             // an error somewhere: everybody winds down
+    int rc = PMAP_OK;
+    std::string error;
+    // pinned buffers
+    std::vector<Batch *> all_buffers, free_buffers;
+    size_t max_buffers = 4;
+    // parsed pieces waiting for the sequencer, by piece number
+    std::map<uint64_t, Batch *> parsed;
+    // sequenced batches waiting for a mapper
+    std::deque<Batch *> ready;
+    bool sequenced_all = false;
+    uint64_t n_batches = 0;         // valid once sequenced_all
+    // mapped batches waiting to be retired, by batch number
+    std::map<uint64_t, Outcome *> done;
+    uint64_t covg = 0;
+    double waited_parse = 0, waited_map = 0, waited_retire = 0;
+
+    void fail(int code, const std::string &msg) {
+        std::lock_guard<std::mutex> l(m);
+        if (rc == PMAP_OK) {
+            rc = code;
+            error = msg;
+        }
+        abort = true;
+        cv.notify_all();
+    }
+    Batch *get_buffer(size_t want) {        // nullptr: aborted, or out of pinned memory (fail() has been called)
+        Batch *b = nullptr;
+        {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return abort || !free_buffers.empty() || all_buffers.size() < max_buffers; });
+            if (abort) return nullptr;
+            if (!free_buffers.empty()) {
+                b = free_buffers.back();
+                free_buffers.pop_back();
+            } else {
+                b = new Batch();
+                all_buffers.push_back(b);
             }
         }
-        // a read without a sketch consumes an id too (:409-412): it travels in the batch so that ids stay
-        // consecutive, and yields nothing
-        if (b->size + seq.size() > b->cap && b->size > 0 && !flush()) break;
-        if (!b->reserve(b->size + seq.size() + 64)) {
-            out->rc = PMAP_EHIP;
-            out->error = "out of pinned host memory for a read batch";
+        b->reset();
+        if (!b->reserve(want)) {
+            fail(PMAP_EHIP, "out of pinned host memory for a read batch");
+            return nullptr;
+        }
+        return b;
+    }
+    void put_buffer(Batch *b) {
+        { std::lock_guard<std::mutex> l(m); free_buffers.push_back(b); }
+        cv.notify_all();
+    }
+    void push_ready(Batch *b) {
+        { std::lock_guard<std::mutex> l(m); ready.push_back(b); }
+        cv.notify_all();
+    }
+    void finish_sequencing(uint64_t batches, uint64_t covg_) {
+        { std::lock_guard<std::mutex> l(m); sequenced_all = true; n_batches = batches; covg = covg_; }
+        cv.notify_all();
+    }
+    ~Pipeline() {
+        for (Batch *b : all_buffers) {
+            b->release();
+            delete b;
+        }
+        for (auto &kv : done) delete kv.second;
+    }
+};
+
+// ---- source 1: a gzip (or unmappable) file, parsed and sequenced by one thread
+
+void stream_source(Pipeline *pl, FastaqReader<LineStream> *fh, pmap_params_t prm0) {
+    ReadLoop loop{pl->a, prm0};
+    uint64_t seq = 0;
+    Batch *b = pl->get_buffer(pl->batch_bases + (1u << 20));
+    auto flush = [&]() -> bool {      // hands the batch over and takes an empty one
+        b->prm = loop.prm;
+        b->seq = seq++;
+        pl->push_ready(b);
+        b = pl->get_buffer(pl->batch_bases + (1u << 20));
+        if (b) b->first_id = loop.id;
+        return b != nullptr;
+    };
+    if (b) b->first_id = 0;
+    while (b && !fh->eof()) {
+        fh->get_next();
+        const std::string &seq_ = fh->read;
+        // Seq::initialize -> the sketch is non-empty iff the read has a full window and only ACGT letters
+        const bool sketched = seq_.size() + 1 >= (uint64_t) pl->a->w + pl->a->k &&
+                              all_acgt((const unsigned char *) seq_.data(), seq_.size());
+        if (!loop.take(seq_.size(), sketched)) break;
+        if (b->size + seq_.size() > b->cap && b->size > 0) {
+            loop.id--;                   // the batch in hand ends before this read
+            const bool ok = flush();
+            loop.id++;
+            if (!ok) break;
+        }
+        if (!b->append(seq_, sketched)) {
+            pl->fail(PMAP_EHIP, "out of pinned host memory for a read batch");
             break;
         }
-        b->append(seq);
-        id++;
-        if (sketched && id > 10000000) break;                           // :420-423
-        if (b->size >= batch_bases && !flush()) break;
+        if (loop.stopped) break;
+        if (b->size >= pl->batch_bases && !flush()) break;
     }
-    if (fh->in.io_error && out->rc == PMAP_OK) {
-        out->rc = PMAP_EIO;
-        out->error = "error while reading the fastaq file";
-    }
+    if (fh->in.io_error) pl->fail(PMAP_EIO, "error while reading the fastaq file");
     if (b) {
-        b->prm = prm;
-        q->put_ready(b);
+        if (b->n_reads() > 0) {
+            b->prm = loop.prm;
+            b->seq = seq++;
+            pl->push_ready(b);
+        } else {
+            pl->put_buffer(b);
+        }
     }
-    out->covg = covg;
-    q->finish();
+    pl->finish_sequencing(seq, loop.covg);
 }
 
-// host side of one mapped batch: filter_clusters -> add_node calls (+ Read::hits, + coverage)
-int finish_batch(const pmap_index_t *idx, pmap_result_t *res, pmap_pangraph *pg, bool keep_hits,
-                 pmap_coverage_t *cov) {
+// ---- source 2: a plain file mapped into memory, parsed in pieces by several threads
+
+struct MappedFile {
+    const char *base = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    bool open(const char *path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return false;
+        void *p = mmap(nullptr, (size_t) st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) return false;
+        base = (const char *) p;
+        size = (size_t) st.st_size;
+        (void) madvise(p, size, MADV_SEQUENTIAL);
+        return true;
+    }
+    ~MappedFile() {
+        if (base) munmap((void *) base, size);
+        if (fd >= 0) close(fd);
+    }
+};
+
+// The first seam at or behind `from`: a line start whose line begins with '>' or '@' and is not the file's
+// last line; `end` if there is none.  (Behind a seam line that ends the file the reader's next step depends
+// on whether a record was open in front of it, which the parser of the piece behind the seam cannot know;
+// with at least one more line behind the seam line it does not.)
+const char *find_seam(const char *from, const char *end) {
+    const char *p = from;
+    while (p < end) {
+        const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
+        if (!nl || nl + 1 >= end) return end;
+        if (nl[1] == '>' || nl[1] == '@') {
+            const char *nl2 = (const char *) memchr(nl + 1, '\n', (size_t) (end - (nl + 1)));
+            if (!nl2 || nl2 + 1 >= end) return end;
+            return nl + 1;
+        }
+        p = nl + 1;
+    }
+    return end;
+}
+
+// runs the state machine over the piece [begin, end) (+ the seam line behind it) into the batch
+void parse_piece(Batch *b, const char *begin, const char *end, const char *file_end, uint32_t w, uint32_t k) {
+    b->piece_begin = begin;
+    b->piece_end = end;
+    b->piece_last = end >= file_end;
+    FastaqReader<MemLines> fh;
+    fh.in.p = begin;
+    fh.in.piece_end = end;
+    fh.in.last = b->piece_last;
+    if (b->piece_last) {
+        fh.in.limit = file_end;
+    } else {
+        const char *nl = (const char *) memchr(end, '\n', (size_t) (file_end - end));
+        fh.in.limit = nl ? nl + 1 : file_end;
+    }
+    b->exit_code = NEXT_RECORD;
+    // every get_next of the reference's loop `while (!fh.eof()) { fh.get_next(); ... }` that completes inside
+    // the piece or on its seam line; a call that is still under way at the seam goes on in the next piece,
+    // whose parser starts from the state the seam line leaves behind whatever came before it
+    while (fh.in.last ? !fh.eof() : !fh.in.at_limit()) {
+        const int code = fh.get_next();
+        if (code != NEXT_RECORD) {
+            b->exit_code = code;
+            break;
+        }
+        const std::string &r = fh.read;
+        // (blank lines make the reader return a read twice: a piece's reads can outgrow the piece)
+        if (!b->append(r, r.size() + 1 >= (uint64_t) w + k && all_acgt((const unsigned char *) r.data(), r.size()))) {
+            b->exit_code = NEXT_NO_MEMORY;
+            break;
+        }
+    }
+}
+
+// The pieces of a mapped file one after the other on the calling thread, with the same seam rule as the
+// threaded pipeline: emit(batch) for every stretch of the file that was parsed from a true record boundary.
+template <typename Emit>
+bool parse_in_pieces(const char *base, size_t size, uint64_t piece_bytes, uint32_t w, uint32_t k, Batch *b, Emit emit) {
+    const char *cur = base, *file_end = base + size;
+    while (cur < file_end) {
+        const char *begin = cur;
+        const char *end = begin + piece_bytes >= file_end ? file_end : find_seam(begin + piece_bytes, file_end);
+        for (;;) {
+            b->reset();
+            if (!b->reserve((size_t) (end - begin) + 64)) return false;
+            parse_piece(b, begin, end, file_end, w, k);
+            if (b->exit_code == NEXT_NO_MEMORY) return false;
+            if (b->exit_code != NEXT_BAD_SEAM) break;
+            // the seam lay inside a record: take the next piece in as well
+            end = end + piece_bytes >= file_end ? file_end : find_seam(end + piece_bytes, file_end);
+        }
+        emit(*b);
+        cur = end;
+    }
+    return true;
+}
+
+struct PieceSource {
+    Pipeline *pl;
+    MappedFile *file;
+    std::mutex m;                  // hands out the pieces
+    const char *cur = nullptr;
+    uint64_t next_piece = 0;
+    bool stop = false;             // the sequencer has seen the end of the read loop
+
+    void worker() {
+        const char *file_end = file->base + file->size;
+        for (;;) {
+            // the buffer first, then the piece: whoever holds the lowest unparsed piece always has a buffer
+            Batch *b = pl->get_buffer(pl->piece_bytes + (1u << 16));
+            if (!b) return;
+            const char *begin, *end;
+            {
+                std::lock_guard<std::mutex> l(m);
+                if (stop || cur >= file_end) {
+                    pl->put_buffer(b);
+                    return;
+                }
+                begin = cur;
+                end = begin + pl->piece_bytes >= file_end ? file_end : find_seam(begin + pl->piece_bytes, file_end);
+                cur = end;
+                b->seq = next_piece++;
+            }
+            // a read is never longer than its piece
+            if (!b->reserve((size_t) (end - begin) + 64)) {
+                pl->fail(PMAP_EHIP, "out of pinned host memory for a read batch");
+                return;
+            }
+            parse_piece(b, begin, end, file_end, pl->a->w, pl->a->k);
+            if (b->exit_code == NEXT_NO_MEMORY) {
+                pl->fail(PMAP_EHIP, "out of pinned host memory for a read batch");
+                return;
+            }
+            {
+                std::lock_guard<std::mutex> l(pl->m);
+                pl->parsed[b->seq] = b;
+            }
+            pl->cv.notify_all();
+        }
+    }
+
+    // all pieces have been handed out and none with this number will ever arrive
+    bool no_such_piece(uint64_t i) {
+        std::lock_guard<std::mutex> l(m);
+        return (stop || cur >= file->base + file->size) && i >= next_piece;
+    }
+
+    Batch *wait_piece(uint64_t i) {      // nullptr: there is no piece i (end of file), or abort
+        std::unique_lock<std::mutex> l(pl->m);
+        const double t0 = now_s();
+        for (;;) {
+            auto it = pl->parsed.find(i);
+            if (it != pl->parsed.end()) {
+                Batch *b = it->second;
+                pl->parsed.erase(it);
+                pl->waited_parse += now_s() - t0;
+                return b;
+            }
+            if (pl->abort) return nullptr;
+            l.unlock();
+            const bool none = no_such_piece(i);
+            l.lock();
+            if (none && pl->parsed.find(i) == pl->parsed.end()) return nullptr;
+            pl->cv.wait_for(l, std::chrono::milliseconds(2));
+        }
+    }
+
+    void sequencer(pmap_params_t prm0) {
+        ReadLoop loop{pl->a, prm0};
+        const char *file_end = file->base + file->size;
+        uint64_t piece = 0, seq = 0;
+        while (!loop.stopped) {
+            Batch *b = wait_piece(piece++);
+            if (!b) break;
+            // a seam inside a record (the line behind a '+' line starts with '@' or '>'): the piece behind it
+            // was parsed from a wrong state.  Both are parsed again as one piece, here.
+            while (b->exit_code == NEXT_BAD_SEAM) {
+                Batch *nb = wait_piece(piece++);
+                if (!nb) {
+                    pl->fail(PMAP_EIO, "internal: a piece of the read file has no successor");
+                    pl->put_buffer(b);
+                    b = nullptr;
+                    break;
+                }
+                const char *begin = b->piece_begin, *end = nb->piece_end;
+                pl->put_buffer(nb);
+                b->reset();
+                if (!b->reserve((size_t) (end - begin) + 64)) {
+                    pl->fail(PMAP_EHIP, "out of pinned host memory for a read batch");
+                    pl->put_buffer(b);
+                    b = nullptr;
+                    break;
+                }
+                parse_piece(b, begin, end, file_end, pl->a->w, pl->a->k);
+                if (b->exit_code == NEXT_NO_MEMORY) {
+                    pl->fail(PMAP_EHIP, "out of pinned host memory for a read batch");
+                    pl->put_buffer(b);
+                    b = nullptr;
+                    break;
+                }
+            }
+            if (!b) break;
+            b->first_id = loop.id;
+            size_t n = 0;
+            for (; n < b->n_reads(); ++n) {
+                if (!loop.take((size_t) (b->offsets[n + 1] - b->offsets[n]), b->sketchable[n] != 0)) break;
+                if (loop.stopped) { ++n; break; }
+            }
+            b->truncate(n);
+            if (n == 0) {
+                pl->put_buffer(b);
+                continue;
+            }
+            b->prm = loop.prm;
+            b->seq = seq++;
+            pl->push_ready(b);
+        }
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+        }
+        pl->finish_sequencing(seq, loop.covg);
+        // pieces that were parsed beyond the stop
+        std::lock_guard<std::mutex> l(pl->m);
+        for (auto &kv : pl->parsed) pl->free_buffers.push_back(kv.second);
+        pl->parsed.clear();
+        pl->cv.notify_all();
+    }
+};
+
+// host side of one mapped batch: filter_clusters -> the add_node calls it will make (+ Read::hits, + coverage)
+int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool keep_hits, pmap_coverage_t *cov) {
     pmap_counts_t cn;
     int rc = pmap_result_counts(res, &cn);   // waits for the batch
     if (rc) return rc;
@@ -499,22 +877,26 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, pmap_pangraph *pg,
                                    lpos.data(), order.data(), alive.data())))
         return rc;
     std::vector<uint32_t> hpos, hrec;
+    size_t kept_hits = 0;
     if (keep_hits) {
         hpos.resize(nh);
         hrec.resize(nh);
         if ((rc = pmap_result_hits(res, 1, nullptr, hpos.data(), nullptr, hrec.data(), nullptr))) return rc;
+        for (size_t j = 0; j < nc; ++j)
+            if (alive[j]) kept_hits += size[order[j]];
+        out->hits.reserve(kept_hits);
     }
     for (size_t j = 0; j < nc; ++j) {
         if (!alive[j]) continue;
         const uint64_t c = order[j];
-        pg_add_node(pg, prg[c], rid[c], size[c], fwd[c] != 0);
-        if (keep_hits) {
-            if (!pg->hits.reserve_more(size[c])) return pmap_fail(PMAP_ELIMIT, "out of host memory for the hits of the reads");
+        out->prg.push_back(prg[c]);
+        out->read.push_back(rid[c]);
+        out->size.push_back(size[c]);
+        out->fwd.push_back(fwd[c]);
+        if (keep_hits)
             for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
-                pg->hits.push_unchecked(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
-        }
+                out->hits.push_back(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
     }
-    pg->by_path_valid = false;
     if (cov) {
         // add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383) walks Node::reads, a multiset that
         // holds a read once per add_node call, and for each entry every hit of the read on that node: a
@@ -530,18 +912,118 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, pmap_pangraph *pg,
     return PMAP_OK;
 }
 
+// one mapping context's thread: whole batches, one after the other
+void mapper_thread(Pipeline *pl, void *ctx, std::vector<uint32_t> *cov_fwd, std::vector<uint32_t> *cov_rev) {
+    pmap_reads_t *rd = nullptr;
+    pmap_result_t *res = nullptr;
+    pmap_coverage_t *cov = nullptr;
+    int rc = pmap_bind_context(ctx);
+    if (rc == PMAP_OK && pl->want_cov) rc = pmap_coverage_create(pl->idx, &cov);
+    while (rc == PMAP_OK) {
+        Batch *b = nullptr;
+        {
+            std::unique_lock<std::mutex> l(pl->m);
+            const double t0 = now_s();
+            // not too far ahead of the thread that retires the batches
+            pl->cv.wait(l, [&] { return pl->abort || ((!pl->ready.empty() && pl->done.size() < 8) || (pl->ready.empty() && pl->sequenced_all)); });
+            pl->waited_map += now_s() - t0;
+            if (pl->abort || pl->ready.empty()) break;
+            b = pl->ready.front();
+            pl->ready.pop_front();
+        }
+        const uint32_t n = (uint32_t) b->n_reads();
+        if (!rd) rc = pmap_reads_create(b->data, b->offsets.data(), n, b->first_id, &rd);
+        else rc = pmap_reads_update(rd, b->data, b->offsets.data(), n, b->first_id);
+        const pmap_params_t prm = b->prm;
+        const uint64_t seq = b->seq;
+        pl->put_buffer(b);                                          // the upload has finished
+        Outcome *out = new Outcome();
+        if (rc == PMAP_OK) rc = pmap_map(pl->idx, rd, &prm, &res);
+        if (rc == PMAP_OK) rc = finish_batch(pl->idx, res, out, pl->keep_hits, cov);
+        if (rc != PMAP_OK) {
+            delete out;
+            break;
+        }
+        {
+            std::lock_guard<std::mutex> l(pl->m);
+            pl->done[seq] = out;
+        }
+        pl->cv.notify_all();
+    }
+    if (rc == PMAP_OK && cov) {
+        cov_fwd->assign(pl->idx->n_recs, 0);
+        cov_rev->assign(pl->idx->n_recs, 0);
+        rc = pmap_coverage_fetch(cov, cov_fwd->data(), cov_rev->data());
+    }
+    if (rc != PMAP_OK) pl->fail(rc, pmap_last_error());
+    pmap_coverage_destroy(cov);
+    pmap_result_destroy(res);
+    pmap_reads_destroy(rd);
+}
+
+unsigned parse_threads() {
+    if (const char *e = getenv("PMAP_PARSE_THREADS")) return (unsigned) std::max(0, atoi(e));
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    if (const char *e = getenv("OMP_NUM_THREADS")) {       // this process' share of a big host
+        const int v = atoi(e);
+        if (v > 0) hw = std::min<unsigned>(hw, (unsigned) v);
+    }
+    return std::max(1u, std::min(hw, 16u) * 3 / 4);
+}
+
+bool looks_gzipped(const char *path) {
+    unsigned char magic[2] = {0, 0};
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    const size_t n = fread(magic, 1, 2, f);
+    fclose(f);
+    return n == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+}
+
 }  // namespace
+
+static int read_fastaq_pieces(const char *path, uint64_t piece_bytes, char **bases, uint64_t **offsets, uint32_t *n_reads) {
+    MappedFile mapped;
+    std::string all;
+    std::vector<uint64_t> off{0};
+    if (!mapped.open(path)) {
+        // empty or unmappable: nothing to cut into pieces, but the file must exist
+        FILE *f = fopen(path, "rb");
+        if (!f) return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + path);
+        fclose(f);
+    } else {
+        Batch b;
+        b.pinned = false;
+        const bool ok = parse_in_pieces(mapped.base, mapped.size, piece_bytes, 1, 1, &b, [&](const Batch &p) {
+            const uint64_t base0 = all.size();
+            all.append(p.data, p.size);
+            for (size_t i = 1; i < p.offsets.size(); ++i) off.push_back(base0 + p.offsets[i]);
+        });
+        b.release();
+        if (!ok) return pmap_fail(PMAP_ELIMIT, "out of memory while reading the fastaq file");
+    }
+    if (n_reads) *n_reads = (uint32_t) (off.size() - 1);
+    if (bases) {
+        *bases = (char *) malloc(all.size() + 1);
+        memcpy(*bases, all.data(), all.size());
+        (*bases)[all.size()] = 0;
+    }
+    if (offsets) {
+        *offsets = (uint64_t *) malloc(sizeof(uint64_t) * off.size());
+        memcpy(*offsets, off.data(), sizeof(uint64_t) * off.size());
+    }
+    return PMAP_OK;
+}
 
 extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx,
                                             const pmap_map_args_t *a, pmap_pangraph_t **out, uint32_t *covg_out) {
     if (!reads_path || !idx || !a || !out) return pmap_fail(PMAP_EINVAL, "null argument");
     if (a->clean) return pmap_fail(PMAP_EINVAL, "clean=true (de Bruijn cleaning of the pangraph) is outside this library");
     if (a->w == 0 || a->genome_size == 0) return pmap_fail(PMAP_EINVAL, "w and genome_size must be positive");
-    int rc = pmap_init(-1);
+    std::vector<void *> contexts;
+    int rc = pmap_contexts_for_file(&contexts);
     if (rc) return rc;
-    FastaqReader fh;
-    if (!fh.open(reads_path))
-        return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + reads_path);
 
     pmap_params_t prm;
     memset(&prm, 0, sizeof(prm));
@@ -551,63 +1033,102 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     prm.fraction = pmap_fraction(a->e_rate, a->k);                 // src/utils.cpp:394
     prm.min_cluster_size = a->min_cluster_size;
     prm.expected_kmers = std::numeric_limits<uint32_t>::max();     // :395
-    // 32 Mbases per batch: the reader's pinned buffers stay cache- and TLB-friendly on the host (a 2 GB FASTQ maps at
-    // 2.9 Gbases/s with 32-Mbase batches and at 1.6 with 256-Mbase ones) and the GPU is far from busy either way
-    const uint64_t batch_bases = a->batch_bases ? a->batch_bases : (32ull << 20);
-    const bool keep_hits = !(a->flags & PMAP_PG_NO_HITS);
+
+    Pipeline pl;
+    pl.idx = idx;
+    pl.a = a;
+    pl.keep_hits = !(a->flags & PMAP_PG_NO_HITS);
+    pl.want_cov = (a->flags & PMAP_PG_COVERAGE) != 0;
+    // 32 Mbases per batch: the pinned buffers stay cache- and TLB-friendly on the host (a 2 GB FASTQ mapped at
+    // 2.9 Gbases/s with 32-Mbase batches and at 1.6 with 256-Mbase ones) and the GPU is far from busy either way.
+    // A piece of a mapped file becomes one batch: with qualities and headers about two bytes per base.
+    pl.batch_bases = a->batch_bases ? a->batch_bases : (32ull << 20);
+    pl.piece_bytes = a->batch_bases ? a->batch_bases : (64ull << 20);
+
+    // the file must open (src/fastaq_handler.cpp:18-21) before any thread starts
+    FastaqReader<LineStream> fh;
+    MappedFile mapped;
+    const unsigned n_parse = parse_threads();
+    const bool parallel = n_parse > 0 && !looks_gzipped(reads_path) && mapped.open(reads_path);
+    if (!parallel && !fh.in.open(reads_path))
+        return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + reads_path);
 
     pmap_pangraph *pg = new pmap_pangraph();
-    pg->keep_hits = keep_hits;
-    if ((a->flags & PMAP_PG_COVERAGE) && (rc = pmap_coverage_create(idx, &pg->cov))) {
-        delete pg;
-        return rc;
-    }
-    Batch batches[3];
-    BatchQueue q;
-    for (Batch &b : batches) {
-        if (!b.reserve(batch_bases + (1u << 20))) {
-            for (Batch &x : batches) if (x.data) pmap_pinned_free(x.data);
-            delete pg;
-            return pmap_fail(PMAP_EHIP, "out of pinned host memory for the read batches");
-        }
-        q.free_list.push_back(&b);
-    }
-    ReaderResult rr;
-    std::thread reader(reader_thread, &fh, a, prm, batch_bases, &q, &rr);
+    pg->keep_hits = pl.keep_hits;
+    pg->has_cov = pl.want_cov;
+    const double t_start = now_s();
 
-    pmap_reads_t *rds[2] = {nullptr, nullptr};
-    pmap_result_t *ress[2] = {nullptr, nullptr};
-    int slot = 0, pending = -1;
-    while (Batch *b = q.get_ready()) {
-        const uint32_t n = (uint32_t) (b->offsets.size() - 1);
-        if (n == 0) { q.put_free(b); continue; }
-        if (!rds[slot]) rc = pmap_reads_create(b->data, b->offsets.data(), n, b->first_id, &rds[slot]);
-        else rc = pmap_reads_update(rds[slot], b->data, b->offsets.data(), n, b->first_id);
-        const pmap_params_t bprm = b->prm;
-        q.put_free(b);                                             // the upload has finished
-        if (rc == PMAP_OK) rc = pmap_map_async(idx, rds[slot], &bprm, &ress[slot]);
-        if (rc == PMAP_OK && pending >= 0) rc = finish_batch(idx, ress[pending], pg, keep_hits, pg->cov);
-        if (rc) break;
-        pending = slot;
-        slot ^= 1;
+    std::vector<std::thread> threads;
+    PieceSource src{&pl, &mapped};
+    if (parallel) {
+        src.cur = mapped.base;
+        const unsigned workers = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(n_parse, mapped.size / std::max<uint64_t>(pl.piece_bytes, 1) + 1));
+        pl.max_buffers = workers + 2 * contexts.size() + 2;
+        for (unsigned i = 0; i < workers; ++i) threads.emplace_back(&PieceSource::worker, &src);
+        threads.emplace_back(&PieceSource::sequencer, &src, prm);
+    } else {
+        pl.max_buffers = 2 * contexts.size() + 2;
+        threads.emplace_back(stream_source, &pl, &fh, prm);
     }
-    if (rc == PMAP_OK && pending >= 0) rc = finish_batch(idx, ress[pending], pg, keep_hits, pg->cov);
-    q.stop();
-    reader.join();
+    std::vector<std::vector<uint32_t>> cov_fwd(contexts.size()), cov_rev(contexts.size());
+    for (size_t i = 0; i < contexts.size(); ++i)
+        threads.emplace_back(mapper_thread, &pl, contexts[i], &cov_fwd[i], &cov_rev[i]);
+
+    // retire: the add_node calls (src/utils.cpp:346-351) of every batch, in file order
+    for (uint64_t next = 0;;) {
+        Outcome *o = nullptr;
+        {
+            std::unique_lock<std::mutex> l(pl.m);
+            const double t0 = now_s();
+            pl.cv.wait(l, [&] { return pl.abort || pl.done.count(next) || (pl.sequenced_all && next >= pl.n_batches); });
+            pl.waited_retire += now_s() - t0;
+            if (pl.abort || !pl.done.count(next)) break;
+            o = pl.done[next];
+            pl.done.erase(next);
+        }
+        pl.cv.notify_all();
+        for (size_t j = 0; j < o->prg.size(); ++j) pg_add_node(pg, o->prg[j], o->read[j], o->size[j], o->fwd[j] != 0);
+        if (!o->hits.empty()) {
+            if (!pg->hits.reserve_more(o->hits.size())) {
+                pl.fail(PMAP_ELIMIT, "out of host memory for the hits of the reads");
+                delete o;
+                break;
+            }
+            memcpy(pg->hits.p + pg->hits.n, o->hits.data(), o->hits.size() * sizeof(PgHit));
+            pg->hits.n += o->hits.size();
+        }
+        delete o;
+        ++next;
+    }
+    {
+        // whatever ended the loop, every thread must be able to leave: buffers and queues are released by `abort`
+        std::lock_guard<std::mutex> l(pl.m);
+        if (pl.rc != PMAP_OK) pl.abort = true;
+    }
+    pl.cv.notify_all();
+    for (auto &t : threads) t.join();
+    pg->by_path_valid = false;
     if (getenv("PMAP_TRACE_PIPELINE"))
-        fprintf(stderr, "[pmap] read-file pipeline: the mapping thread waited %.3f s for batches, the reader %.3f s for free buffers\n",
-                q.mapper_waited, q.reader_waited);
-    if (rc == PMAP_OK && rr.rc) rc = pmap_fail(rr.rc, rr.error);
-    for (int i = 0; i < 2; ++i) {
-        pmap_result_destroy(ress[i]);
-        pmap_reads_destroy(rds[i]);
-    }
-    for (Batch &b : batches) if (b.data) pmap_pinned_free(b.data);
-    if (rc) {
+        fprintf(stderr, "[pmap] read-file pipeline: %.3f s, %s, %zu mapping contexts; waited: sequencer for pieces %.3f s, "
+                        "mappers for batches %.3f s (all of them together), retiring thread for mapped batches %.3f s\n",
+                now_s() - t_start, parallel ? "mapped file parsed in pieces" : "one parsing thread", contexts.size(),
+                pl.waited_parse, pl.waited_map, pl.waited_retire);
+    if (pl.rc != PMAP_OK) {
+        const int code = pl.rc;
+        const std::string msg = pl.error;
         pmap_pangraph_destroy(pg);
-        return rc;
+        return pmap_fail(code, msg);
     }
-    if (covg_out) *covg_out = (uint32_t) (rr.covg / a->genome_size);      // :442, 454
+    if (pl.want_cov) {
+        pg->cov_fwd.assign(idx->n_recs, 0);
+        pg->cov_rev.assign(idx->n_recs, 0);
+        for (size_t i = 0; i < contexts.size(); ++i)
+            for (size_t j = 0; j < cov_fwd[i].size(); ++j) {
+                pg->cov_fwd[j] += cov_fwd[i][j];
+                pg->cov_rev[j] += cov_rev[i][j];
+            }
+    }
+    if (covg_out) *covg_out = (uint32_t) (pl.covg / a->genome_size);      // :442, 454
     *out = pg;
     return PMAP_OK;
 }
@@ -704,12 +1225,13 @@ extern "C" int pmap_pangraph_call_hits(const pmap_pangraph_t *pg, uint64_t *hit_
 // KmerNode coverage after add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383), per index record
 extern "C" int pmap_pangraph_coverage(const pmap_pangraph_t *pg, uint32_t *forward, uint32_t *reverse) {
     if (!pg) return pmap_fail(PMAP_EINVAL, "null argument");
-    if (!pg->cov) return pmap_fail(PMAP_EINVAL, "the pangraph was built without PMAP_PG_COVERAGE");
-    return pmap_coverage_fetch(pg->cov, forward, reverse);
+    if (!pg->has_cov) return pmap_fail(PMAP_EINVAL, "the pangraph was built without PMAP_PG_COVERAGE");
+    if (forward) memcpy(forward, pg->cov_fwd.data(), pg->cov_fwd.size() * sizeof(uint32_t));
+    if (reverse) memcpy(reverse, pg->cov_rev.data(), pg->cov_rev.size() * sizeof(uint32_t));
+    return PMAP_OK;
 }
 
 extern "C" void pmap_pangraph_destroy(pmap_pangraph_t *pg) {
     if (!pg) return;
-    pmap_coverage_destroy(pg->cov);
     delete pg;
 }

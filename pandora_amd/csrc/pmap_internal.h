@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,11 +81,16 @@ struct pmap_index {
     // presence filter: pmap_filter_mask(key) is set in word pmap_filter_word(key) for every key; 0 = no filter
     uint32_t filter_bits = 0;
     std::vector<uint32_t> filter;
-    // device
-    PmapSlot *d_slots = nullptr;
-    PmapRec *d_recs = nullptr;
-    uint32_t *d_filter = nullptr;
-    uint64_t device_bytes = 0;
+    // device copies, one per GPU the index has been used on (uploaded on first use, under `upload_mu`)
+    struct OnDevice {
+        PmapSlot *slots = nullptr;
+        PmapRec *recs = nullptr;
+        uint32_t *filter = nullptr;
+    };
+    static const int MAX_DEVICES = 64;
+    OnDevice dev[MAX_DEVICES];
+    std::mutex upload_mu;
+    uint64_t device_bytes = 0;      // per device
 };
 
 // pinned host memory (hipHostMalloc), nullptr on failure
@@ -96,8 +102,14 @@ int pmap_fail(int code, const std::string &msg);
 
 // host side of index construction (pmap_index.cpp); uploads via pmap_index_upload (pmap_device.hip)
 int pmap_index_build_host(const pmap_index_desc_t *desc, pmap_index *idx);
-int pmap_index_upload(pmap_index *idx);
+int pmap_index_upload(pmap_index *idx);          // to the calling thread's current device
 void pmap_index_release_device(pmap_index *idx);
+
+// The mapping contexts (opaque) pmap_pangraph_from_read_file spreads its batches over: those of
+// pmap_init_devices, or two on the calling thread's GPU.  pmap_bind_context makes one of them the calling
+// thread's current context.
+int pmap_contexts_for_file(std::vector<void *> *out);
+int pmap_bind_context(void *ctx);
 
 // (float) threshold of one prg, src/utils.cpp:211-213,219-220
 static inline uint32_t pmap_threshold(uint32_t mpl, uint32_t expected, float fraction, uint32_t min_cluster_size) {

@@ -1,7 +1,11 @@
 """Read sharding for N GPUs of one node: reads are independent at every stage of the path, so a batch
 is cut into contiguous read-id ranges balanced by bases, every rank maps its range against its own
 replica of the index, and the per-rank cluster tables are concatenated in read-id order on rank 0.
-No collective touches the data path; torch.distributed only carries the final tables."""
+No collective touches the data path; torch.distributed only carries the final tables.
+
+What is sequential in pangraph_from_read_file (read ids, the coverage stop, the 10M-read stop, the Illumina
+k-mer count taken from the first sketched read; src/utils.cpp:397-440) is decided before the reads are
+sharded: a shard is a range of reads that are all going to be mapped, with their final ids."""
 import numpy as np
 
 
@@ -27,13 +31,27 @@ def shard(bases, offsets, rank, world):
     return bases[lo:hi], offsets[b:e + 1] - offsets[b], b
 
 
-def gather_tables(local, dst=0):
-    """Gathers per-rank dicts of equally keyed numpy arrays on rank `dst` and concatenates them in rank
-    order (= read-id order, since shards are contiguous ranges).  Returns None on other ranks."""
+def merge_tables(parts, n_hits=None):
+    """Concatenates per-shard dicts of equally keyed numpy arrays in shard order (= read-id order, since
+    shards are contiguous ranges).  A `begin` column (first hit of a cluster in its shard's sorted hits,
+    MapResult.clusters()) is moved to the numbering of the concatenated hits: n_hits[i] = hits of shard i."""
+    out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    if "begin" in out:
+        if n_hits is None:
+            raise ValueError("merging cluster tables with a `begin` column needs the hit count of every shard")
+        base = np.concatenate([[0], np.cumsum(n_hits)[:-1]]).astype(out["begin"].dtype)
+        out["begin"] = np.concatenate([p["begin"] + base[i] for i, p in enumerate(parts)])
+    return out
+
+
+def gather_tables(local, dst=0, n_hits=None):
+    """Gathers per-rank dicts on rank `dst` and merges them (merge_tables); n_hits = this rank's hit count
+    when the tables have a `begin` column.  Returns None on other ranks."""
     import torch.distributed as dist
     world = dist.get_world_size()
     parts = [None] * world if dist.get_rank() == dst else None
-    dist.gather_object(local, parts, dst=dst)
+    dist.gather_object((local, n_hits), parts, dst=dst)
     if parts is None:
         return None
-    return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    counts = [c for _, c in parts]
+    return merge_tables([t for t, _ in parts], None if any(c is None for c in counts) else counts)

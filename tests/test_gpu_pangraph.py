@@ -204,3 +204,57 @@ def test_gzip_and_repeated_clusters_coverage(gpu, tmp_path):
     np.testing.assert_array_equal(got_fwd, want_fwd)
     np.testing.assert_array_equal(got_rev, want_rev)
     assert got_fwd.max() >= 2
+
+
+def test_contexts_and_parsers_give_one_result(gpu, tmp_path, monkeypatch):
+    """pangraph_from_read_file spreads the pieces of a file over parser threads and its batches over mapping
+    contexts (here three of them on the one GPU, the default two, and one); a gzip-free file can also go
+    through the single parsing thread that gzip files use.  Same pangraph every way, equal to the oracle's."""
+    from pandora_amd import sharding
+    rng = np.random.default_rng(31)
+    loci = synth.make_loci(30, rng, dup_frac=0.1, family_frac=0.3)
+    vloci = synth.make_variant_loci(loci, rng)
+    si = synth.build_variant_index(vloci, 14, 15)
+    genome = synth.make_variant_genome(vloci, rng)
+    bases, off = synth.simulate_reads(genome, 150, rng, mean_len=2000, e_rate=0.06, n_frac=0.05, short_frac=0.05)
+    p = tmp_path / "reads.fq"
+    _write_fastq(p, bases, off, rng)          # quality lines start with '@': most cuts of the file are wrong ones
+    idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                           si.iv_start, si.iv_len, si.min_path_length)
+    res, covg, _ = _expected_from_oracle(si, p.read_bytes(), 14, 15, 250, 0.11, 10, 5000, False, 300)
+    want_fwd, want_rev = O.oracle_coverage(res, len(si.rec_prg))
+
+    def run(batch):
+        pg = api.pangraph_from_read_file(p, idx, 14, 15, 250, 0.11, 10, 5000, batch_bases=batch, coverage=True)
+        n = _check_pangraph(pg, res, covg)
+        got_fwd, got_rev = pg.coverage()
+        np.testing.assert_array_equal(got_fwd, want_fwd)
+        np.testing.assert_array_equal(got_rev, want_rev)
+        return n
+
+    try:
+        for devices in ([0, 0, 0], [0], []):
+            api.init_devices(devices)
+            for batch in (2500, 40000, 0):
+                assert run(batch) > 50
+        monkeypatch.setenv("PMAP_PARSE_THREADS", "0")
+        assert run(7000) > 50
+        monkeypatch.setenv("PMAP_PARSE_THREADS", "3")
+        assert run(900) > 50
+    finally:
+        api.init_devices([])
+    # objects made before the context juggling still work, and so does the batch API from this thread
+    rd = api.Reads(bases, off)
+    whole = api.map_reads(idx, rd, 14, 15, 250, api.fraction(0.11, 15))
+    # the same batch sharded in two as N GPUs would take it, merged in read-id order
+    parts, counts = [], []
+    for rank in range(2):
+        sb, so, first = sharding.shard(bases, off, rank, 2)
+        r = api.map_reads(idx, api.Reads(sb, so, first_read_id=first), 14, 15, 250, api.fraction(0.11, 15))
+        parts.append(r.clusters())
+        counts.append(r.counts()["n_hits"])
+    merged = sharding.merge_tables(parts, counts)
+    want = whole.clusters()
+    assert len(want["size"]) > 50
+    for f in want:
+        np.testing.assert_array_equal(merged[f], want[f], err_msg=f)

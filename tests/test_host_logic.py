@@ -336,3 +336,60 @@ def test_two_rank_sharding_gloo():
     assert alive.sum() > 5
     for k in merged:
         np.testing.assert_array_equal(merged[k], one[k][alive])
+
+
+def _piece_cases():
+    rng = np.random.default_rng(12)
+    seqs = [bytes(synth.random_dna(int(rng.integers(0, 300)), rng)) for _ in range(60)]
+    fastq = b"".join(b"@r%d extra\n%s\n+\n%s\n" % (i, s, bytes(rng.choice(np.frombuffer(b"@>+!Ia5", np.uint8), len(s))))
+                     for i, s in enumerate(seqs))
+    fasta = b"".join(b">r%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, len(s), 60)) for i, s in enumerate(seqs))
+    mixed = b"".join((b"@q%d\n%s\n+\n%s\n" % (i, s, b"@" * len(s))) if i % 2 else (b">a%d\n%s\n" % (i, s))
+                     for i, s in enumerate(seqs))
+    blanks = b"\n\n>a\nACGT\n\n>b\nGG\nTT\n\n\n@c\nAC\n+\n@@\n\n>d\n>e\nACG\n" * 7
+    return [fastq, fasta, mixed, blanks, fastq[:-1], fasta + b"\n\n", b">only\nACGT", b"\n", b"@a\nAC\n+\n",
+            b"ACGT\nGG\n>x\nTT\n", b"@a\nACGT\n+\n@CGT\n@b\nGGGG\n+\n>>>>\n" * 30]
+
+
+def test_read_fastaq_in_pieces(tmp_path):
+    """The reader of pangraph_from_read_file for plain files parses pieces of the file independently; however
+    the file is cut (quality lines that start with '@' or '>' make wrong cuts that must be noticed), the reads
+    are those of the sequential reader."""
+    for i, buf in enumerate(_piece_cases()):
+        p = tmp_path / ("pieces%d.fq" % i)
+        p.write_bytes(buf)
+        want = [r for _, r in O.fastaq_iterate(buf)]
+        assert [r for _, r in api.read_fastaq(p)] == want
+        for piece in (1, 2, 3, 7, 19, 64, 257, 1000, 5000, 1 << 20):
+            assert api.read_fastaq_pieces(p, piece) == want, (i, piece)
+    for name in ["reads.fa", "reads.fq", "read2.fa", "read2.fq", "read0.fa", "test.fastq", "oxa9_read.fasta",
+                 "loman_k12_merged_pass.mm2.sorted_1196-1216.fastq"]:
+        path = os.path.join(FIX, name)
+        want = [r for _, r in O.fastaq_iterate(open(path, "rb").read())]
+        for piece in (1, 5, 50, 333, 4096):
+            assert api.read_fastaq_pieces(path, piece) == want, (name, piece)
+    empty = tmp_path / "empty.fq"
+    empty.write_bytes(b"")
+    assert api.read_fastaq_pieces(empty, 10) == [] == [r for _, r in O.fastaq_iterate(b"")]
+    with pytest.raises(api.PmapError):
+        api.read_fastaq_pieces(tmp_path / "missing.fq", 10)
+
+
+def test_read_fastaq_in_pieces_random_files(tmp_path):
+    """Files made of random lines of every kind the reader distinguishes (headers of both kinds, '+' lines,
+    blank lines, sequence, lines that only look like headers), with and without a final newline."""
+    rng = np.random.default_rng(2025)
+    kinds = [b"@h", b">h", b"+", b"", b"ACGT", b"GGA", b"@@@@", b">>", b"+x", b"\t", b"+", b"ACGTACGTAC"]
+    weights = np.array([3, 3, 3, 2, 6, 3, 2, 1, 1, 1, 2, 3], float)
+    weights /= weights.sum()
+    for case in range(150):
+        n = int(rng.integers(0, 40))
+        lines = [kinds[i] for i in rng.choice(len(kinds), n, p=weights)]
+        buf = b"\n".join(lines) + (b"\n" if rng.random() < 0.6 and n else b"")
+        p = tmp_path / ("rnd%d.fq" % case)
+        p.write_bytes(buf)
+        want = [r for _, r in O.fastaq_iterate(buf)]
+        if buf:
+            assert [r for _, r in api.read_fastaq(p)] == want, buf
+        for piece in (1, 2, 4, 9, 30, 1000):
+            assert api.read_fastaq_pieces(p, piece) == want, (buf, piece)
