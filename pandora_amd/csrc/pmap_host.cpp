@@ -187,15 +187,24 @@ struct MemLines {
 
 enum { NEXT_RECORD = 0, NEXT_AT_SEAM = 1, NEXT_BAD_SEAM = 2, NEXT_NO_MEMORY = 3 };
 
-// FastaqHandler::get_next (src/fastaq_handler.cpp:43-71) over either source
-template <typename Src>
+// FastaqHandler's `read` member as a plain string
+struct StringAcc {
+    std::string s;
+    bool empty() const { return s.empty(); }
+    void clear() { s.clear(); }
+    void append(const char *p, size_t n) { s.append(p, n); }
+};
+
+// FastaqHandler::get_next (src/fastaq_handler.cpp:43-71) over either source; Acc holds the `read` member
+template <typename Src, typename Acc = StringAcc>
 struct FastaqReader {
     Src in;
     // the last line read: only its first character and its emptiness matter to get_next
     bool line_empty = true;
     char line_first = 0;
     std::string pending_name;     // the header line that ended the record before
-    std::string name, read;
+    std::string name;
+    Acc read;
     bool eof() { return in.at_eof(); }
     int get_next() {
         if (!line_empty && (line_first == '>' || line_first == '@')) {
@@ -239,7 +248,7 @@ extern "C" int pmap_read_fastaq(const char *path, char **bases, uint64_t **offse
     std::vector<uint64_t> off{0}, noff{0};
     while (!fh.eof()) {
         fh.get_next();
-        all += fh.read;
+        all += fh.read.s;
         off.push_back(all.size());
         allnames += fh.name;
         noff.push_back(allnames.size());
@@ -392,6 +401,35 @@ double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Pinned buffers are expensive to make (the driver locks and maps every page): the ones a call is done with
+// are kept for the next call, up to 4 GiB of them.
+struct PinnedCache {
+    std::mutex m;
+    std::vector<std::pair<char *, size_t>> free_list;
+    size_t held = 0;
+    char *take(size_t want, size_t *got) {
+        std::lock_guard<std::mutex> l(m);
+        size_t best = free_list.size();
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].second >= want && (best == free_list.size() || free_list[i].second < free_list[best].second))
+                best = i;
+        if (best == free_list.size()) return nullptr;
+        char *p = free_list[best].first;
+        *got = free_list[best].second;
+        held -= *got;
+        free_list.erase(free_list.begin() + best);
+        return p;
+    }
+    bool give(char *p, size_t bytes) {       // false: not kept, the caller frees it
+        std::lock_guard<std::mutex> l(m);
+        if (bytes < (1u << 20) || held + bytes > (4ull << 30)) return false;
+        free_list.push_back({p, bytes});
+        held += bytes;
+        return true;
+    }
+};
+PinnedCache g_pinned_cache;
+
 struct Batch {
     char *data = nullptr;          // pinned (plain memory when `pinned` is off: parsing without a GPU)
     bool pinned = true;
@@ -411,20 +449,27 @@ struct Batch {
         sketchable.clear();
         exit_code = NEXT_RECORD;
     }
-    bool reserve(size_t want) {
+    // `live`: bytes from the start of the buffer that must survive a move (a read under construction lies
+    // behind `size`)
+    bool reserve(size_t want, size_t live = 0) {
         if (want <= cap) return true;
         size_t ncap = std::max(want, cap + cap / 2);
-        char *q = (char *) (pinned ? pmap_pinned_alloc(ncap) : malloc(ncap));
+        char *q = pinned ? g_pinned_cache.take(want, &ncap) : nullptr;
+        if (!q) q = (char *) (pinned ? pmap_pinned_alloc(ncap) : malloc(ncap));
         if (!q) return false;
-        if (size) memcpy(q, data, size);
+        live = std::min(std::max(live, size), cap);
+        if (live) memcpy(q, data, live);
         release();
         data = q;
         cap = ncap;
         return true;
     }
     void release() {
-        if (data && pinned) pmap_pinned_free(data);
-        else if (data) free(data);
+        if (data && pinned) {
+            if (!g_pinned_cache.give(data, cap)) pmap_pinned_free(data);
+        } else if (data) {
+            free(data);
+        }
         data = nullptr;
         cap = 0;
     }
@@ -469,6 +514,46 @@ bool all_acgt(const unsigned char *p, size_t n) {
     }
     return !bad;
 }
+
+// FastaqHandler's `read` member kept inside a batch's buffer: the lines of a read are copied once, to where
+// the batch wants them.  The member outlives the call that returned it (a blank line makes the next call
+// return it again, or append to it): a returned read stays readable where it is, and is copied to the end
+// of the buffer only if the reader touches it again.
+struct BatchAcc {
+    Batch *b = nullptr;
+    size_t start = 0, len = 0;
+    bool returned = false;      // [start, start + len) is already a read of the batch
+    bool oom = false;
+    bool empty() const { return len == 0; }
+    void clear() {
+        start = b->size;
+        len = 0;
+        returned = false;
+    }
+    void unshare() {
+        if (!b->reserve(b->size + len + 64, start + len)) { oom = true; return; }
+        memmove(b->data + b->size, b->data + start, len);
+        start = b->size;
+        returned = false;
+    }
+    void append(const char *p, size_t n) {
+        if (returned) unshare();
+        if (oom) return;
+        if (start + len + n > b->cap && !b->reserve(start + len + n + 64, start + len)) { oom = true; return; }
+        memcpy(b->data + start + len, p, n);
+        len += n;
+    }
+    // the reader returned: the member's content is the batch's next read
+    bool emit(uint32_t w, uint32_t k) {
+        if (returned) unshare();
+        if (oom) return false;
+        b->size = start + len;
+        b->offsets.push_back(b->size);
+        b->sketchable.push_back(len + 1 >= (uint64_t) w + k && all_acgt((const unsigned char *) b->data + start, len));
+        returned = true;
+        return true;
+    }
+};
 
 // The read loop of pangraph_from_read_file (src/utils.cpp:397-440) up to the point where a read is handed
 // to the sketch: ids, coverage stop, 10M-read stop, Illumina expected k-mer count.
@@ -596,7 +681,7 @@ void stream_source(Pipeline *pl, FastaqReader<LineStream> *fh, pmap_params_t prm
     if (b) b->first_id = 0;
     while (b && !fh->eof()) {
         fh->get_next();
-        const std::string &seq_ = fh->read;
+        const std::string &seq_ = fh->read.s;
         // Seq::initialize -> the sketch is non-empty iff the read has a full window and only ACGT letters
         const bool sketched = seq_.size() + 1 >= (uint64_t) pl->a->w + pl->a->k &&
                               all_acgt((const unsigned char *) seq_.data(), seq_.size());
@@ -675,7 +760,9 @@ void parse_piece(Batch *b, const char *begin, const char *end, const char *file_
     b->piece_begin = begin;
     b->piece_end = end;
     b->piece_last = end >= file_end;
-    FastaqReader<MemLines> fh;
+    FastaqReader<MemLines, BatchAcc> fh;
+    fh.read.b = b;
+    fh.read.clear();
     fh.in.p = begin;
     fh.in.piece_end = end;
     fh.in.last = b->piece_last;
@@ -695,13 +782,13 @@ void parse_piece(Batch *b, const char *begin, const char *end, const char *file_
             b->exit_code = code;
             break;
         }
-        const std::string &r = fh.read;
         // (blank lines make the reader return a read twice: a piece's reads can outgrow the piece)
-        if (!b->append(r, r.size() + 1 >= (uint64_t) w + k && all_acgt((const unsigned char *) r.data(), r.size()))) {
+        if (!fh.read.emit(w, k)) {
             b->exit_code = NEXT_NO_MEMORY;
             break;
         }
     }
+    if (fh.read.oom) b->exit_code = NEXT_NO_MEMORY;
 }
 
 // The pieces of a mapped file one after the other on the calling thread, with the same seam rule as the

@@ -24,27 +24,31 @@ def main():
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--no-hits", action="store_true")
     ap.add_argument("--batch-mbases", type=int, default=0, help="0 = the library's default")
+    ap.add_argument("--contexts", type=int, default=0, help="mapping contexts on GPU 0 (0 = the library's default, two)")
     args = ap.parse_args()
     import pandora_amd
     from pandora_amd import api, synth
     pandora_amd.init(0)
+    if args.contexts:
+        api.init_devices([0] * args.contexts)
     si, bases, off, prm = synth.workload("nanopore_1k", seed=1)
     d = tempfile.mkdtemp(prefix="pmap_file_bench_")
     path = os.path.join(d, "reads.fq" + (".gz" if args.gz else ""))
     t0 = time.perf_counter()
     opener = (lambda p: gzip.open(p, "wb", compresslevel=1)) if args.gz else (lambda p: open(p, "wb"))
+    one = b"".join(b"@r%d\n" % i + bases[int(off[i]):int(off[i + 1])].tobytes() + b"\n+\n" +
+                   b"I" * int(off[i + 1] - off[i]) + b"\n" for i in range(len(off) - 1))
     with opener(path) as f:
         for c in range(args.copies):
-            for i in range(len(off) - 1):
-                seq = bases[int(off[i]):int(off[i + 1])].tobytes()
-                f.write(b"@r%d_%d\n" % (c, i) + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+            f.write(one)
     write_s = time.perf_counter() - t0
     size = os.path.getsize(path)
     gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
                             si.iv_start, si.iv_len, si.min_path_length)
     n_bases = int(off[-1]) * args.copies
     out = {"file_bytes": size, "bases": n_bases, "reads": (len(off) - 1) * args.copies, "gz": args.gz,
-           "keep_hits": not args.no_hits, "write_s": write_s, "runs": []}
+           "keep_hits": not args.no_hits, "write_s": write_s, "contexts": args.contexts or 2,
+           "parse_threads": os.environ.get("PMAP_PARSE_THREADS", "default"), "runs": []}
     for rep in range(3):
         t0 = time.perf_counter()
         pg = api.pangraph_from_read_file(path, gidx, prm["w"], prm["k"], prm["max_diff"], prm["e_rate"],
