@@ -182,6 +182,10 @@ typedef struct {
 /* Diagnostic: sort with the kernel variant for indexes of more than 2^19 loci (keys too wide to share a
  * word with a position) whatever the index. */
 #define PMAP_FLAG_SORT_WIDE 8u
+/* Test hook: the prefix sums that chain the workgroups of the cluster kernels give up at their first wait, as
+ * they would after a very long one, so that the batch takes the fallback (one workgroup per kernel) it takes
+ * then.  Results are the same. */
+#define PMAP_FLAG_TEST_CHAIN_GIVES_UP 16u
 
 /* 0.5 / exp(e_rate * k) as src/utils.cpp:394 evaluates it (float). */
 float pmap_fraction(float e_rate, uint32_t k);
@@ -230,7 +234,8 @@ typedef struct {
     uint64_t n_clusters;        /* kept by define_clusters */
     /* HIP-event times of the last pmap_map with profile=1, milliseconds (sums of
      * the kernels of each phase): 0 sketch, 1 probe (scan+scatter), 2 sort,
-     * 3 cluster, 4 first kernel start to last kernel stop */
+     * 3 cluster, 4 first kernel start to last kernel stop.  ms[5] is no time: the number of batches this
+     * result object has had to map again without chained prefix sums so far */
     float ms[PMAP_N_TIMERS];
 } pmap_counts_t;
 int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out);

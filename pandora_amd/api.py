@@ -263,13 +263,13 @@ class MapResult:
 
 
 def map_reads(index, reads, w, k, max_diff, fraction_required, min_cluster_size=10, expected_kmers=UINT32_MAX,
-              last_stage=0, profile=0, result=None, unfused=False, wait=True, sketch=None, sort_wide=False):
+              last_stage=0, profile=0, result=None, unfused=False, wait=True, sketch=None, sort_wide=False, flags=0):
     """Seq::minimizer_sketch -> add_read_hits -> MinimizerHits::sort -> define_clusters on the GPU.
     wait=False only enqueues the kernels (pmap_map_async): call result.wait(), or any accessor, later;
     index and reads must stay alive until then.  sketch="np8" | "lds" picks another of the equivalent
     sketch kernels (PMAP_FLAG_SKETCH_*)."""
     res = result if result is not None else MapResult()
-    flags = (1 if unfused else 0) | {None: 0, "np8": 2, "lds": 4}[sketch] | (8 if sort_wide else 0)
+    flags |= (1 if unfused else 0) | {None: 0, "np8": 2, "lds": 4}[sketch] | (8 if sort_wide else 0)
     prm = _lib.Params(w, k, max_diff, fraction_required, min_cluster_size, expected_kmers, last_stage, profile,
                       flags)
     fn = _lib.load().pmap_map if wait else _lib.load().pmap_map_async

@@ -281,7 +281,8 @@ struct Counters {
     unsigned long long n_cl;      // clusters before the size threshold
     unsigned long long n_kept;    // clusters kept
     uint32_t fail;                // a chained prefix sum gave up waiting
-    uint32_t pad[5];
+    uint32_t has_long;            // some read has more hits than the rank-counting sort takes: the long-segment kernels have work
+    uint32_t pad[4];
 };
 static_assert(sizeof(Counters) == 64, "Counters is the head of the state block");
 
@@ -317,6 +318,7 @@ static SketchKind sketch_kind(uint32_t w, uint32_t k, uint32_t flags, uint32_t *
 struct pmap_reads {
     DevCtx *ctx = nullptr;
     uint32_t n_reads = 0, first_read_id = 0;
+    uint32_t max_len = 0;      // longest read of the batch
     uint64_t n_bases = 0;
     uint32_t n_words = 0;      // packed words, each read padded to a multiple of 16 bases
     uint32_t n_tiles = 0;
@@ -355,6 +357,7 @@ struct pmap_result {
     DevBuf h_read, h_key, h_pos, h_rank, h_rec;
     DevBuf hbounds;   // per read: first hit, then ~(one past the last hit); all-ones before every run
     DevBuf s_read, s_key, s_pos, s_rank, s_rec;
+    DevBuf long_words;   // sort of reads with very many hits: the hit array's blocks, each sorted (8 bytes per hit)
     // clusters
     DevBuf cstart, k_rows;
     DevBuf thr;
@@ -374,10 +377,12 @@ struct pmap_result {
     pmap_params_t p_prm;
     bool p_fused = false;
     uint32_t p_last = 0;
+    bool serial_scans = false;        // this run replaces the chained prefix sums by one workgroup per kernel
+    uint32_t n_serial_reruns = 0;     // batches that needed that so far
     uint32_t kt_recorded = 0;
     std::vector<DevBuf *> all() {
         return {&state, &group_sum, &tile_cnt, &bsum, &scratch_total, &mkmer, &ents, &h_read, &h_key, &h_pos, &h_rank, &h_rec,
-                &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &cstart, &k_rows, &thr};
+                &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &long_words, &cstart, &k_rows, &thr};
     }
 };
 
@@ -467,6 +472,7 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
     rlen.assign(n_reads + 1, 0);
     boff.assign(n_reads + 1, 0);
     uint64_t words = 0;
+    uint32_t max_len = 0;
     const uint64_t base0 = offsets[0];
     for (uint32_t r = 0; r < n_reads; ++r) {
         if (offsets[r + 1] < offsets[r]) return pmap_fail(PMAP_EINVAL, "read offsets not monotone");
@@ -474,6 +480,7 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
         if (len >= 0x7FFFFFFEull) return pmap_fail(PMAP_ELIMIT, "a read is longer than 2^31-3 bases");
         woff[r] = (uint32_t) words;
         rlen[r] = (uint32_t) len;
+        max_len = std::max(max_len, (uint32_t) len);
         boff[r] = offsets[r] - base0;
         words += (len + 15) / 16;
         if (words * 16 >= 0xFFFFF000ull)
@@ -487,6 +494,7 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
     rd->first_read_id = first_read_id;
     rd->n_bases = n_bases;
     rd->n_words = (uint32_t) words;
+    rd->max_len = max_len;
     rd->n_tiles = 0;   // the tiling depends on w: pmap_map computes it
     const size_t ascii_bytes = ((n_bases + 3) & ~3ull) + 64;
     const size_t word_slots = (size_t) words + 16;
@@ -772,29 +780,51 @@ static int run_pipeline(pmap_result *res) {
     &dc->n_hits, res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),      \
         res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,          \
         res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), \
-        res->s_rec.as<uint32_t>()
+        res->s_rec.as<uint32_t>(), &dc->has_long
         // keys are prg << 1 | strand: narrow enough to share a word with a place in the staged chunk?
         if (2ull * idx->n_prg <= (1ull << (31 - SORT_CH_BITS)) && !(prm->flags & PMAP_FLAG_SORT_WIDE))
             KLAUNCH(sort_rank_kernel<true>, dim3(res->hit_cap / 256), SORT_ARGS);
         else
             KLAUNCH(sort_rank_kernel<false>, dim3(res->hit_cap / 256), SORT_ARGS);
 #undef SORT_ARGS
+        // reads with more hits than the rank counting takes; launched only if such a read can exist (a read
+        // has at most one minimizer per base and a minimizer at most max_cnt hits)
+        if ((uint64_t) rd->max_len * idx->max_cnt > SORT_LONG) {
+            KLAUNCH(long_presort_kernel, dim3(res->hit_cap / SORT_LB), dc, res->hit_cap, res->h_read.as<uint32_t>(),
+                    res->h_key.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
+                    res->long_words.as<unsigned long long>());
+            KLAUNCH(long_rank_kernel, dim3(res->hit_cap / 256), dc, res->hit_cap, res->h_read.as<uint32_t>(),
+                    res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(),
+                    res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
+                    res->long_words.as<unsigned long long>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
+                    res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->s_rec.as<uint32_t>());
+        }
         kt.end(KT_SORT);
         HIP_TRY(hipGetLastError());
     }
 
     // ---- cluster
     if (last >= PMAP_STAGE_CLUSTER && n_tiles) {
+        // the chained prefix sums wait for earlier workgroups; a batch whose wait ran out is mapped again with
+        // one workgroup per kernel that walks the blocks itself (pmap_map_wait sets serial_scans)
+        const uint32_t spin = (prm->flags & PMAP_FLAG_TEST_CHAIN_GIVES_UP) ? 0u : CHAIN_SPIN_LIMIT;
+#define CUT_ARGS                                                                                                      \
+    dc, res->hit_cap, res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(),              \
+        (int) prm->max_diff, gran_a, res->cl_cap, res->cstart.as<uint32_t>(), res->n_ablk, spin
+#define KEEP_ARGS                                                                                                     \
+    dc, res->cl_cap, res->hit_cap, res->cstart.as<uint32_t>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), \
+        res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), gran_b,                       \
+        res->k_rows.as<uint32_t>(), res->n_bblk, spin
         kt.begin(KT_CLUSTER_CUT);
-        KLAUNCH_B(cluster_cut_kernel, dim3(res->n_ablk), CUT_THREADS, dc, res->hit_cap, res->s_read.as<uint32_t>(),
-                res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), (int) prm->max_diff, gran_a, res->cl_cap,
-                res->cstart.as<uint32_t>());
+        if (res->serial_scans) KLAUNCH_B(cluster_cut_kernel<true>, dim3(1), CUT_THREADS, CUT_ARGS);
+        else KLAUNCH_B(cluster_cut_kernel<false>, dim3(res->n_ablk), CUT_THREADS, CUT_ARGS);
         kt.end(KT_CLUSTER_CUT);
         kt.begin(KT_CLUSTER_KEEP);
-        KLAUNCH_B(cluster_keep_kernel, dim3(res->n_bblk), KEEP_THREADS, dc, res->cl_cap, res->hit_cap, res->cstart.as<uint32_t>(),
-                res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(),
-                res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), gran_b, res->k_rows.as<uint32_t>());
+        if (res->serial_scans) KLAUNCH_B(cluster_keep_kernel<true>, dim3(1), KEEP_THREADS, KEEP_ARGS);
+        else KLAUNCH_B(cluster_keep_kernel<false>, dim3(res->n_bblk), KEEP_THREADS, KEEP_ARGS);
         kt.end(KT_CLUSTER_KEEP);
+#undef CUT_ARGS
+#undef KEEP_ARGS
         HIP_TRY(hipGetLastError());
     }
     res->kt_recorded = kt.recorded;
@@ -809,7 +839,7 @@ static int ensure_hit_buffers(pmap_result *res, uint32_t hit_cap) {
     if ((rc = res->h_read.ensure(hb)) || (rc = res->h_key.ensure(hb)) || (rc = res->h_pos.ensure(hb)) ||
         (rc = res->h_rank.ensure(hb)) || (rc = res->h_rec.ensure(hb)) || (rc = res->s_read.ensure(hb)) ||
         (rc = res->s_key.ensure(hb)) || (rc = res->s_pos.ensure(hb)) || (rc = res->s_rank.ensure(hb)) ||
-        (rc = res->s_rec.ensure(hb)))
+        (rc = res->s_rec.ensure(hb)) || (rc = res->long_words.ensure(2 * hb)))
         return rc;
     res->hit_cap = hit_cap;
     return PMAP_OK;
@@ -917,7 +947,20 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(hipEventSynchronize(res->done));
         const Counters &hc = *res->hc;
-        if (hc.fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
+        if (hc.fail) {
+            // a workgroup waited in vain for the prefix of an earlier one (another process on the GPU, or a
+            // dispatch order the chain does not expect): the same batch once more without a chain
+            if (res->serial_scans) {
+                res->serial_scans = false;
+                return pmap_fail(PMAP_EHIP, "the cluster kernels failed without a chained prefix sum");
+            }
+            res->serial_scans = true;
+            res->n_serial_reruns++;
+            rc = run_pipeline(res);
+            if (rc) { res->serial_scans = false; return rc; }
+            continue;
+        }
+        res->serial_scans = false;
         n_mini = hc.n_mini;
         n_hits = hc.n_hits;
         if (n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
@@ -945,6 +988,7 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
     cn.n_clusters_all = last >= PMAP_STAGE_CLUSTER ? hc.n_cl : 0;
     cn.n_clusters = last >= PMAP_STAGE_CLUSTER ? hc.n_kept : 0;
     res->have_minimizers = !res->p_fused;
+    cn.ms[5] = (float) res->n_serial_reruns;
     if (res->p_prm.profile >= 1) {
         const uint32_t recorded = res->kt_recorded;
         for (int i = 0; i < KT_COUNT; ++i) {
@@ -1017,6 +1061,9 @@ static int noalloc_setup(DevCtx *ctx) {
     DevBuf *unsorted[5] = {&v->h_read, &v->h_key, &v->h_pos, &v->h_rank, &v->h_rec};
     for (int i = 0; i < 5; ++i) unsorted[i]->view(base + NA_OFF_HITS + (size_t) i * 4 * NA_MAX_HITS, 4 * NA_MAX_HITS);
     v->ents.view(base + NA_OFF_ENTS, 32 * NA_MAX_SLOTS);
+    // the tile entries are dead once the hits have been emitted: the sort's block words take their place
+    static_assert(8 * NA_MAX_HITS <= 32 * NA_MAX_SLOTS, "the long-segment sort's words fit the entry area");
+    v->long_words.view(base + NA_OFF_ENTS, 8 * NA_MAX_HITS);
     // never used on this path (unfused mode, minimizer gather); empty views make any use fail instead of allocate
     v->mkmer.view(nullptr, 0);
     v->bsum.view(nullptr, 0);
@@ -1098,8 +1145,15 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     res->p_last = PMAP_STAGE_CLUSTER;
     if ((rc = run_pipeline(res))) return rc;
     HIP_TRY(hipEventSynchronize(res->done));
+    if (res->hc->fail) {                      // as pmap_map_wait: once more without a chain between workgroups
+        res->serial_scans = true;
+        rc = run_pipeline(res);
+        res->serial_scans = false;
+        if (rc) return rc;
+        HIP_TRY(hipEventSynchronize(res->done));
+        if (res->hc->fail) return pmap_fail(PMAP_EHIP, "the cluster kernels failed without a chained prefix sum");
+    }
     const Counters &hc = *res->hc;
-    if (hc.fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
     counts->n_reads = rd->n_reads;
     counts->n_bases = rd->n_bases;
     counts->n_minimizers = hc.n_mini;

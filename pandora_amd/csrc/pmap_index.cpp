@@ -202,6 +202,7 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         ukeys.push_back(key);
         uoff.push_back((uint32_t) idx->recs.size());
         ucnt.push_back((uint32_t) tmp.size());
+        idx->max_cnt = std::max(idx->max_cnt, (uint32_t) tmp.size());
         for (uint32_t j : tmp) {
             PmapRec r;
             r.prg = d->rec_prg[j];
@@ -579,6 +580,7 @@ extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out)
         for (const PmapSlot &sl : idx->slots)
             if (sl.key != PMAP_EMPTY_KEY) {
                 ++used;
+                idx->max_cnt = std::max(idx->max_cnt, sl.cnt);
                 if ((uint64_t) sl.off + sl.cnt > h.n_recs || sl.cnt == 0) ok = false;
                 else if (memcmp(&sl.first, &idx->recs[sl.off], sizeof(PmapRec)) != 0) ok = false;
             }

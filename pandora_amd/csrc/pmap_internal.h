@@ -68,6 +68,7 @@ struct pmap_index {
     uint32_t n_prg = 0;
     uint64_t n_keys = 0, n_recs = 0, n_paths = 0;
     uint32_t log2cap = 0;
+    uint32_t max_cnt = 0;       // most records under one key
     // host copies, caller's record numbering
     std::vector<uint64_t> key_of_rec;
     std::vector<uint32_t> rec_prg, rec_knode, path_rank;

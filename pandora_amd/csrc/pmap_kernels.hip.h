@@ -197,7 +197,7 @@ static const uint32_t CHAIN_SPIN_LIMIT = 1u << 18;
 static const int CHAIN_SLABS = 8;     // one look-back round reads 8 x 64 predecessors, all loads in flight together
 
 __device__ __forceinline__ uint32_t chained_scan(unsigned long long *gran, uint32_t b, uint32_t total,
-                                                 uint32_t *fail, uint32_t *lds2) {
+                                                 uint32_t *fail, uint32_t *lds2, uint32_t spin_limit) {
     if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         uint32_t excl = 0;
@@ -219,7 +219,7 @@ __device__ __forceinline__ uint32_t chained_scan(unsigned long long *gran, uint3
                         ready = ready && (g[i] >> 32) != 0;
                     }
                     if (__all(ready)) break;
-                    if (++spins > CHAIN_SPIN_LIMIT) {           // uniform: every lane counts alike
+                    if (++spins > spin_limit) {                 // uniform: every lane counts alike
                         if (lane == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                         for (int i = 0; i < CHAIN_SLABS; ++i)
@@ -275,6 +275,11 @@ __device__ __forceinline__ uint32_t clamp_count(const unsigned long long *p, uin
 // one that holds the hit, which counts smaller keys only / smaller and equal ones.
 static const int SORT_CH_BITS = 11, SORT_CH = 1 << SORT_CH_BITS;
 
+// A read with more than SORT_LONG hits is left to the long-segment kernels below (rank counting costs a
+// comparison per pair of hits of a read: fine for the hundreds of hits of a usual read, not for the 10^5 of
+// a megabase read on an index with several records per key); *has_long tells them that there is work.
+static const uint32_t SORT_LONG = 4096;
+
 template <bool NARROW>
 __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long *__restrict__ n_hits_p,
                                                         uint32_t hit_cap, const uint32_t *__restrict__ h_read,
@@ -285,24 +290,39 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
                                                         const uint32_t *__restrict__ hbounds, uint32_t n_reads,
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
-                                                        uint32_t *__restrict__ s_rec) {
+                                                        uint32_t *__restrict__ s_rec, uint32_t *__restrict__ has_long) {
     __shared__ uint32_t keys[SORT_CH];
-    __shared__ uint32_t range[2];
+    __shared__ uint32_t wlo[4], whi[4];
     const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
     if (blockIdx.x * 256 >= n_hits) return;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool active = i < n_hits;
+    bool active = i < n_hits;
     uint32_t r = 0, key = 0, s = 0, e = 0;
     if (active) {
         r = h_read[i];
         key = h_key[i];
         s = hbounds[r];
         e = ~hbounds[n_reads + r];
+        if (e - s > SORT_LONG) {
+            active = false;
+            *has_long = 1u;             // every writer stores the same value
+        }
     }
-    if (threadIdx.x == 0) range[0] = s;
-    if (active && (threadIdx.x == 255 || i == n_hits - 1)) range[1] = e;
+    // the stretch of hits this block's reads cover: from the first active thread's read to the last one's
+    // (hits are ordered by read, so are the bounds)
+    {
+        const unsigned long long m = ballot64(active);
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (m == 0) {
+            if (lane == 0) { wlo[wv] = 0xFFFFFFFFu; whi[wv] = 0u; }
+        } else {
+            if (lane == (uint32_t) __builtin_ctzll(m)) wlo[wv] = s;
+            if (lane == 63u - (uint32_t) __builtin_clzll(m)) whi[wv] = e;
+        }
+    }
     __syncthreads();
-    const uint32_t smin = range[0], emax = range[1];
+    const uint32_t smin = min(min(wlo[0], wlo[1]), min(wlo[2], wlo[3]));
+    const uint32_t emax = max(max(whi[0], whi[1]), max(whi[2], whi[3]));
     const uint32_t PLACE = (2u << SORT_CH_BITS) - 1;      // SORT_CH_BITS + 1 bits: all-ones is above every place
     uint32_t c = 0;
     for (uint32_t base = smin; base < emax; base += SORT_CH) {
@@ -336,6 +356,106 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
 }
 
 // ---------------------------------------------------------------------------
+// Long segments.  The hit array is cut into fixed blocks of SORT_LB hits.  long_presort_kernel sorts, for
+// every block that touches a long segment, the words {read - first read of the block, key, place in the
+// block} (ascending: hits are ordered by read already, so this orders each read's part of the block by key
+// and keeps the emission order inside a key).  long_rank_kernel then finds a hit's place in its read's
+// sorted segment by binary searches, two per block the segment touches, instead of one comparison per hit
+// of the segment: the hits of blocks before its own with keys <= its key, of later blocks with keys < its
+// key, and its own position among its read's words in its own block.
+static const uint32_t SORT_LB_BITS = 11, SORT_LB = 1u << SORT_LB_BITS;
+
+__device__ __forceinline__ unsigned long long long_word(uint32_t read_local, uint32_t key, uint32_t place) {
+    return ((unsigned long long) read_local << (32 + SORT_LB_BITS)) | ((unsigned long long) key << SORT_LB_BITS) | place;
+}
+
+__device__ __forceinline__ bool in_long_segment(uint32_t i, const uint32_t *__restrict__ h_read,
+                                                const uint32_t *__restrict__ hbounds, uint32_t n_reads) {
+    const uint32_t r = h_read[i];
+    return ~hbounds[n_reads + r] - hbounds[r] > SORT_LONG;
+}
+
+__global__ __launch_bounds__(256) void long_presort_kernel(const Counters *__restrict__ dc, uint32_t hit_cap,
+                                                           const uint32_t *__restrict__ h_read,
+                                                           const uint32_t *__restrict__ h_key,
+                                                           const uint32_t *__restrict__ hbounds, uint32_t n_reads,
+                                                           unsigned long long *__restrict__ words) {
+    if (!dc->has_long) return;
+    __shared__ unsigned long long w[SORT_LB];
+    const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
+    const uint32_t b0 = blockIdx.x * SORT_LB;
+    if (b0 >= n_hits) return;
+    const uint32_t n = min(SORT_LB, n_hits - b0);
+    // a long segment is longer than a block: if it touches the block, it holds the block's first or last hit
+    if (!in_long_segment(b0, h_read, hbounds, n_reads) && !in_long_segment(b0 + n - 1, h_read, hbounds, n_reads)) return;
+    const uint32_t r0 = h_read[b0];
+    for (uint32_t t = threadIdx.x; t < SORT_LB; t += 256)
+        w[t] = t < n ? long_word(h_read[b0 + t] - r0, h_key[b0 + t], t) : ~0ull;
+    __syncthreads();
+    // bitonic sort of SORT_LB words, 256 threads, 4 compare-exchanges each per step
+    for (uint32_t size = 2; size <= SORT_LB; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < SORT_LB / 2; t += 256) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));        // index with bit `stride` clear
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = w[lo], b = w[hi];
+                if ((a > b) == up) { w[lo] = b; w[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t t = threadIdx.x; t < SORT_LB; t += 256) words[b0 + t] = w[t];
+}
+
+// number of words of the sorted block below `x` (the block has SORT_LB words, padded with all-ones)
+__device__ __forceinline__ uint32_t long_lower_bound(const unsigned long long *__restrict__ blk, unsigned long long x) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = SORT_LB >> 1; step > 0; step >>= 1)
+        if (blk[lo + step - 1] < x) lo += step;
+    return lo + (blk[lo] < x ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(256) void long_rank_kernel(const Counters *__restrict__ dc, uint32_t hit_cap,
+                                                        const uint32_t *__restrict__ h_read,
+                                                        const uint32_t *__restrict__ h_key,
+                                                        const uint32_t *__restrict__ h_pos,
+                                                        const uint32_t *__restrict__ h_rank,
+                                                        const uint32_t *__restrict__ h_rec,
+                                                        const uint32_t *__restrict__ hbounds, uint32_t n_reads,
+                                                        const unsigned long long *__restrict__ words,
+                                                        uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
+                                                        uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
+                                                        uint32_t *__restrict__ s_rec) {
+    if (!dc->has_long) return;
+    const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hits) return;
+    const uint32_t r = h_read[i], key = h_key[i];
+    const uint32_t s = hbounds[r], e = ~hbounds[n_reads + r];
+    if (e - s <= SORT_LONG || e > n_hits) return;
+    const uint32_t own = i >> SORT_LB_BITS;
+    uint32_t c = 0;
+    for (uint32_t blk = s >> SORT_LB_BITS; blk <= (e - 1) >> SORT_LB_BITS; ++blk) {
+        const unsigned long long *wb = words + (size_t) blk * SORT_LB;
+        const uint32_t rl = r - h_read[blk << SORT_LB_BITS];         // this read's number inside the block
+        const uint32_t first = long_lower_bound(wb, long_word(rl, 0u, 0u));
+        uint32_t upto;
+        if (blk < own) upto = long_lower_bound(wb, long_word(rl, key, SORT_LB - 1) + 1);        // keys <= key
+        else if (blk > own) upto = long_lower_bound(wb, long_word(rl, key, 0u));                // keys < key
+        else upto = long_lower_bound(wb, long_word(rl, key, i & (SORT_LB - 1)));                // before hit i in its own block
+        c += upto - first;
+    }
+    const uint32_t d = s + c;
+    if (d >= n_hits) return;
+    s_read[d] = r;
+    s_key[d] = key;
+    s_pos[d] = h_pos[i];
+    s_rank[d] = h_rank[i];
+    s_rec[d] = h_rec[i];
+}
+
+// ---------------------------------------------------------------------------
 // cluster cut (src/utils.cpp:206-209).  A block of 512 threads takes 8192 sorted hits (16 rounds of
 // 512), flags the hits that start a cluster, and writes their indices to cstart at the chained
 // prefix sum of the blocks' flag counts.  The last block writes the cluster total.  Many hits per
@@ -345,16 +465,23 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
 // which leaves 3) it could not start before that kernel had drained: 136 instead of 11 us.
 static const uint32_t CUT_THREADS = 512, CUT_WAVES = CUT_THREADS / 64, CUT_ROUNDS = 16, CUT_BLOCK = CUT_THREADS * CUT_ROUNDS;
 
+// SERIAL: the same work by ONE workgroup that takes the blocks in turn and carries the prefix itself, no
+// chain between workgroups: what a batch falls back to when a chained prefix sum gave up waiting (it
+// relies on workgroups being dispatched in index order, which nothing guarantees).
+template <bool SERIAL>
 __global__ __launch_bounds__(CUT_THREADS) void cluster_cut_kernel(Counters *__restrict__ dc, uint32_t hit_cap,
                                                                   const uint32_t *__restrict__ s_read,
                                                                   const uint32_t *__restrict__ s_key,
                                                                   const uint32_t *__restrict__ s_pos, int max_diff,
                                                                   unsigned long long *__restrict__ gran,
-                                                                  uint32_t cl_cap, uint32_t *__restrict__ cstart) {
+                                                                  uint32_t cl_cap, uint32_t *__restrict__ cstart,
+                                                                  uint32_t n_blocks, uint32_t spin_limit) {
     __shared__ uint32_t s_cnt[CUT_ROUNDS * CUT_WAVES], s_half[2], s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x;
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
+    uint32_t carry = 0;
+    for (uint32_t b = SERIAL ? 0u : blockIdx.x; b < n_blocks; b += SERIAL ? 1u : n_blocks) {
+    if (SERIAL) __syncthreads();          // the counts of the block before have been used
     uint32_t fbits = 0;
     uint8_t rank[CUT_ROUNDS];
     static_assert(CUT_ROUNDS <= 32, "one flag bit per round");
@@ -386,14 +513,24 @@ __global__ __launch_bounds__(CUT_THREADS) void cluster_cut_kernel(Counters *__re
     __syncthreads();
     const uint32_t total = s_half[0] + s_half[1];
     if (wv < 2) s_cnt[threadIdx.x] = ex + (wv ? s_half[0] : 0u);
-    const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);   // has a block barrier after the writes above
+    uint32_t excl;
+    if (SERIAL) {
+        excl = carry;
+        carry += total;
+        __syncthreads();
+    } else {
+        excl = chained_scan(gran, b, total, &dc->fail, s_scan, spin_limit);   // has a block barrier after the writes above
+    }
 #pragma unroll
     for (uint32_t r = 0; r < CUT_ROUNDS; ++r)
         if (fbits >> r & 1u) {
             const uint32_t c = excl + s_cnt[r * CUT_WAVES + wv] + rank[r];
             if (c < cl_cap) cstart[c] = b * CUT_BLOCK + r * CUT_THREADS + threadIdx.x;
         }
-    if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_cl = (unsigned long long) excl + total;
+    // a serial pass stops behind the last hit instead of walking the whole capacity
+    if (SERIAL && (uint64_t) b * CUT_BLOCK + CUT_BLOCK >= n_hits) b = n_blocks - 1;
+    if (b == n_blocks - 1 && threadIdx.x == 0) dc->n_cl = (unsigned long long) excl + total;
+    }
 }
 
 // One thread per cluster, 2 rounds of 512 per block: size threshold (src/utils.cpp:211-220) and,
@@ -402,6 +539,7 @@ __global__ __launch_bounds__(CUT_THREADS) void cluster_cut_kernel(Counters *__re
 // the kept counts.  The last block writes the kept total.
 static const uint32_t KEEP_THREADS = 512, KEEP_WAVES = KEEP_THREADS / 64, KEEP_ROUNDS = 2, KEEP_BLOCK = KEEP_THREADS * KEEP_ROUNDS;
 
+template <bool SERIAL>
 __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
                                                                     uint32_t hit_cap, const uint32_t *__restrict__ cstart,
                                                                     const uint32_t *__restrict__ s_read,
@@ -410,11 +548,14 @@ __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__
                                                                     const uint32_t *__restrict__ s_rank,
                                                                     const uint32_t *__restrict__ thr,
                                                                     unsigned long long *__restrict__ gran,
-                                                                    uint32_t *__restrict__ k_rows) {
+                                                                    uint32_t *__restrict__ k_rows, uint32_t n_blocks,
+                                                                    uint32_t spin_limit) {
     __shared__ uint32_t s_cnt[KEEP_ROUNDS * KEEP_WAVES], s_scan[2];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x;
     const uint32_t n_cl = clamp_count(&dc->n_cl, cl_cap), n_hits = clamp_count(&dc->n_hits, hit_cap);
+    uint32_t carry = 0;
+    for (uint32_t b = SERIAL ? 0u : blockIdx.x; b < n_blocks; b += SERIAL ? 1u : n_blocks) {
+    if (SERIAL) __syncthreads();
     bool kept[KEEP_ROUNDS];
     uint32_t s[KEEP_ROUNDS], e[KEEP_ROUNDS], key[KEEP_ROUNDS], rank[KEEP_ROUNDS];
 #pragma unroll
@@ -442,7 +583,13 @@ __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__
             if (v == r * KEEP_WAVES + wv) before[r] = total;
         total += s_cnt[v];
     }
-    const uint32_t excl = chained_scan(gran, b, total, &dc->fail, s_scan);
+    uint32_t excl;
+    if (SERIAL) {
+        excl = carry;
+        carry += total;
+    } else {
+        excl = chained_scan(gran, b, total, &dc->fail, s_scan, spin_limit);
+    }
 #pragma unroll
     for (uint32_t r = 0; r < KEEP_ROUNDS; ++r)
         if (kept[r]) {
@@ -451,7 +598,10 @@ __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__
             *(uint4 *) row = make_uint4(s[r], e[r] - s[r], s_read[s[r]], key[r]);
             *(uint4 *) (row + 4) = make_uint4(s_pos[s[r]], s_pos[e[r] - 1], s_rank[s[r]], c);
         }
-    if (b == gridDim.x - 1 && threadIdx.x == 0) dc->n_kept = (unsigned long long) excl + total;
+    // a serial pass stops behind the last cluster instead of walking the whole capacity
+    if (SERIAL && (uint64_t) b * KEEP_BLOCK + KEEP_BLOCK >= n_cl) b = n_blocks - 1;
+    if (b == n_blocks - 1 && threadIdx.x == 0) dc->n_kept = (unsigned long long) excl + total;
+    }
 }
 
 #endif

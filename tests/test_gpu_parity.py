@@ -303,3 +303,101 @@ def test_presence_filter_modes(gpu, monkeypatch):
         compare_batch(si, bases, off, 9, 15, 250, api.fraction(0.11, 15), gidx=gidx)     # general sketch kernel
         gidx.close()
     assert seen == {0, 1, 2}, seen
+
+
+def test_megabase_reads(gpu):
+    """Reads of 100 kb and 1 Mb on an index with several records per key: 10^4 to 10^5 hits per read.  Such
+    reads leave the rank-counting sort (a comparison per pair of hits of a read) for the long-segment
+    kernels; shorter reads in the same batch stay where they are."""
+    rng = np.random.default_rng(88)
+    loci = synth.make_loci(150, rng, family_frac=0.5, family_max=8)
+    vloci = synth.make_variant_loci(loci, rng)
+    si = synth.build_variant_index(vloci, 14, 15)
+    genome = synth.make_variant_genome(vloci, rng)
+    big = np.concatenate([genome, synth.revcomp(genome), genome, genome])[:1_000_000]
+    reads = [bytes(genome[:3000]), bytes(big), bytes(genome[1000:101_000]), bytes(synth.revcomp(genome[5000:9000])),
+             bytes(big[200_000:700_000]), bytes(genome[:800])]
+    bases, off = O.pack_reads(reads)
+    cn, orc = compare_batch(si, bases, off, 14, 15, 250, api.fraction(0.11, 15))
+    per_read = np.bincount(orc["hit_read"], minlength=len(reads))
+    assert per_read[1] > 100_000 and 10_000 < per_read[2] < 100_000 and per_read[0] < 4096
+    # what the sort costs with such reads in the batch (for the record: -s shows it)
+    gidx = gpu_index(si)
+    rd = api.Reads(bases, off)
+    res = api.map_reads(gidx, rd, 14, 15, 250, api.fraction(0.11, 15), profile=1)
+    res = api.map_reads(gidx, rd, 14, 15, 250, api.fraction(0.11, 15), profile=1, result=res)
+    print("megabase reads: %d hits, kernel ms %s" % (res.counts()["n_hits"], res.kernel_ms()))
+    assert res.kernel_ms()["sort_rank"] < 20.0
+
+
+def test_chained_scan_fallback(gpu):
+    """When a chained prefix sum of the cluster kernels gives up waiting, the batch is mapped again with one
+    workgroup per kernel that carries the prefix itself; same clusters.  The test hook makes the chain give up
+    at its first wait."""
+    si, bases, off = _small_world(51, 14, 15, n_loci=60, n_reads=1500, mean_len=2000)
+    gidx = gpu_index(si)
+    rd = api.Reads(bases, off)
+    frac = api.fraction(0.11, 15)
+    want = api.map_reads(gidx, rd, 14, 15, 250, frac)
+    assert want.counts()["n_hits"] > 3 * 8192 and want.counts()["n_clusters_all"] > 1024     # several blocks in each chain
+    got = api.map_reads(gidx, rd, 14, 15, 250, frac, flags=16)
+    assert got.counts()["ms"][5] >= 1, "the chain did not give up: the fallback did not run"
+    for f in ("n_hits", "n_clusters_all", "n_clusters"):
+        assert got.counts()[f] == want.counts()[f]
+    a, b = want.clusters(), got.clusters()
+    for f in a:
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    ha, hb = want.hits(), got.hits()
+    for f in ha:
+        np.testing.assert_array_equal(ha[f], hb[f], err_msg=f)
+
+
+def test_two_processes_share_the_gpu(gpu, tmp_path):
+    """Two fresh processes map on the same GPU at the same time (they once hung in their first call when the
+    library gave its streams different priorities)."""
+    import subprocess
+    import sys
+    import os
+    script = tmp_path / "child.py"
+    script.write_text('''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import pandora_amd
+from pandora_amd import api, synth
+pandora_amd.init(0)
+rng = np.random.default_rng(int(sys.argv[1]))
+loci = synth.make_loci(40, rng)
+si = synth.build_index(loci, 14, 15)
+genome = synth.make_genome(loci, rng)
+bases, off = synth.simulate_reads(genome, 300, rng, mean_len=4000, e_rate=0.08)
+gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off, si.iv_start,
+                        si.iv_len, si.min_path_length)
+rd = api.Reads(bases, off)
+frac = api.fraction(0.11, 15)
+first = api.map_reads(gidx, rd, 14, 15, 250, frac).counts()
+ring = [None, None, None]
+for i in range(600):
+    j = i %% 3
+    if ring[j] is not None:
+        c = ring[j].wait().counts()
+        assert (c["n_hits"], c["n_clusters"]) == (first["n_hits"], first["n_clusters"])
+    ring[j] = api.map_reads(gidx, rd, 14, 15, 250, frac, result=ring[j], wait=False)
+for r in ring:
+    c = r.wait().counts()
+    assert (c["n_hits"], c["n_clusters"]) == (first["n_hits"], first["n_clusters"])
+print("child ok", first["n_hits"], int(ring[0].counts()["ms"][5]))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    procs = [subprocess.Popen([sys.executable, str(script), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for seed in (1, 2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=100)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two processes on one GPU: a child did not finish")
+        outs.append(out.decode())
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "child ok" in o, o
