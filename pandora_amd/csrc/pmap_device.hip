@@ -71,6 +71,8 @@ static thread_local hipStream_t g_cur = nullptr;  // where KLAUNCH enqueues
 // takes 8 instead of 16 positions per lane (PMAP_FLAG_SKETCH_* do the same per call).
 enum SketchKind { SKETCH_LDS = 0, SKETCH_DPP8 = 8, SKETCH_DPP16 = 16 };
 static SketchKind g_sketch_pref = SKETCH_DPP16;
+// reads with more hits than this are sorted by the long-segment kernels (PMAP_SORT_LONG overrides, for experiments)
+static uint32_t g_sort_long = 4096;
 
 // ---------------------------------------------------------------------------
 // Scratch memory of pmap_map_noalloc, the entry point that allocates nothing: everything pmap_map keeps
@@ -142,6 +144,7 @@ extern "C" int pmap_init(int device) {
     if (int rc = device_count(&n)) return rc;
     const char *sk = getenv("PMAP_SKETCH");
     g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
+    if (const char *sl = getenv("PMAP_SORT_LONG")) g_sort_long = (uint32_t) std::max(1, atoi(sl));
     if (device < 0) {
         if (t_ctx) return PMAP_OK;
         HIP_TRY(hipGetDevice(&device));
@@ -780,7 +783,7 @@ static int run_pipeline(pmap_result *res) {
     &dc->n_hits, res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),      \
         res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,          \
         res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), \
-        res->s_rec.as<uint32_t>(), &dc->has_long
+        res->s_rec.as<uint32_t>(), &dc->has_long, g_sort_long
         // keys are prg << 1 | strand: narrow enough to share a word with a place in the staged chunk?
         if (2ull * idx->n_prg <= (1ull << (31 - SORT_CH_BITS)) && !(prm->flags & PMAP_FLAG_SORT_WIDE))
             KLAUNCH(sort_rank_kernel<true>, dim3(res->hit_cap / 256), SORT_ARGS);
@@ -789,15 +792,15 @@ static int run_pipeline(pmap_result *res) {
 #undef SORT_ARGS
         // reads with more hits than the rank counting takes; launched only if such a read can exist (a read
         // has at most one minimizer per base and a minimizer at most max_cnt hits)
-        if ((uint64_t) rd->max_len * idx->max_cnt > SORT_LONG) {
+        if ((uint64_t) rd->max_len * idx->max_cnt > g_sort_long) {
             KLAUNCH(long_presort_kernel, dim3(res->hit_cap / SORT_LB), dc, res->hit_cap, res->h_read.as<uint32_t>(),
                     res->h_key.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
-                    res->long_words.as<unsigned long long>());
+                    res->long_words.as<unsigned long long>(), g_sort_long);
             KLAUNCH(long_rank_kernel, dim3(res->hit_cap / 256), dc, res->hit_cap, res->h_read.as<uint32_t>(),
                     res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(),
                     res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
                     res->long_words.as<unsigned long long>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
-                    res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->s_rec.as<uint32_t>());
+                    res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->s_rec.as<uint32_t>(), g_sort_long);
         }
         kt.end(KT_SORT);
         HIP_TRY(hipGetLastError());

@@ -278,7 +278,7 @@ static const int SORT_CH_BITS = 11, SORT_CH = 1 << SORT_CH_BITS;
 // A read with more than SORT_LONG hits is left to the long-segment kernels below (rank counting costs a
 // comparison per pair of hits of a read: fine for the hundreds of hits of a usual read, not for the 10^5 of
 // a megabase read on an index with several records per key); *has_long tells them that there is work.
-static const uint32_t SORT_LONG = 4096;
+static const uint32_t SORT_LONG_DEFAULT = 4096;
 
 template <bool NARROW>
 __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long *__restrict__ n_hits_p,
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
                                                         const uint32_t *__restrict__ hbounds, uint32_t n_reads,
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
-                                                        uint32_t *__restrict__ s_rec, uint32_t *__restrict__ has_long) {
+                                                        uint32_t *__restrict__ s_rec, uint32_t *__restrict__ has_long, uint32_t sort_long) {
     __shared__ uint32_t keys[SORT_CH];
     __shared__ uint32_t wlo[4], whi[4];
     const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
         key = h_key[i];
         s = hbounds[r];
         e = ~hbounds[n_reads + r];
-        if (e - s > SORT_LONG) {
+        if (e - s > sort_long) {
             active = false;
             *has_long = 1u;             // every writer stores the same value
         }
@@ -370,24 +370,32 @@ __device__ __forceinline__ unsigned long long long_word(uint32_t read_local, uin
 }
 
 __device__ __forceinline__ bool in_long_segment(uint32_t i, const uint32_t *__restrict__ h_read,
-                                                const uint32_t *__restrict__ hbounds, uint32_t n_reads) {
+                                                const uint32_t *__restrict__ hbounds, uint32_t n_reads, uint32_t sort_long) {
     const uint32_t r = h_read[i];
-    return ~hbounds[n_reads + r] - hbounds[r] > SORT_LONG;
+    return ~hbounds[n_reads + r] - hbounds[r] > sort_long;
 }
 
 __global__ __launch_bounds__(256) void long_presort_kernel(const Counters *__restrict__ dc, uint32_t hit_cap,
                                                            const uint32_t *__restrict__ h_read,
                                                            const uint32_t *__restrict__ h_key,
                                                            const uint32_t *__restrict__ hbounds, uint32_t n_reads,
-                                                           unsigned long long *__restrict__ words) {
+                                                           unsigned long long *__restrict__ words, uint32_t sort_long) {
     if (!dc->has_long) return;
     __shared__ unsigned long long w[SORT_LB];
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
     const uint32_t b0 = blockIdx.x * SORT_LB;
     if (b0 >= n_hits) return;
     const uint32_t n = min(SORT_LB, n_hits - b0);
-    // a long segment is longer than a block: if it touches the block, it holds the block's first or last hit
-    if (!in_long_segment(b0, h_read, hbounds, n_reads) && !in_long_segment(b0 + n - 1, h_read, hbounds, n_reads)) return;
+    // does a long segment touch the block?  One that is longer than a block holds the block's first or last hit
+    // if it touches it at all; shorter ones (a low threshold) may lie inside: look at every hit then
+    bool touched = in_long_segment(b0, h_read, hbounds, n_reads, sort_long) ||
+                   in_long_segment(b0 + n - 1, h_read, hbounds, n_reads, sort_long);
+    if (sort_long < SORT_LB) {
+        bool mine = false;
+        for (uint32_t t = threadIdx.x; t < n; t += 256) mine = mine || in_long_segment(b0 + t, h_read, hbounds, n_reads, sort_long);
+        touched = __syncthreads_or(mine) != 0;
+    }
+    if (!touched) return;
     const uint32_t r0 = h_read[b0];
     for (uint32_t t = threadIdx.x; t < SORT_LB; t += 256)
         w[t] = t < n ? long_word(h_read[b0 + t] - r0, h_key[b0 + t], t) : ~0ull;
@@ -426,14 +434,14 @@ __global__ __launch_bounds__(256) void long_rank_kernel(const Counters *__restri
                                                         const unsigned long long *__restrict__ words,
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
-                                                        uint32_t *__restrict__ s_rec) {
+                                                        uint32_t *__restrict__ s_rec, uint32_t sort_long) {
     if (!dc->has_long) return;
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_hits) return;
     const uint32_t r = h_read[i], key = h_key[i];
     const uint32_t s = hbounds[r], e = ~hbounds[n_reads + r];
-    if (e - s <= SORT_LONG || e > n_hits) return;
+    if (e - s <= sort_long || e > n_hits) return;
     const uint32_t own = i >> SORT_LB_BITS;
     uint32_t c = 0;
     for (uint32_t blk = s >> SORT_LB_BITS; blk <= (e - 1) >> SORT_LB_BITS; ++blk) {

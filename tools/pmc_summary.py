@@ -19,9 +19,9 @@ import json
 import os
 import sys
 
-PHASE_OF = [("sketch_wave", "sketch"), ("sketch_dpp", "sketch"), ("probe_wave", "probe"), ("scan_", None), ("scatter_group", "probe"),
-            ("group_reduce", "probe"),
-            ("sort_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
+PHASE_OF = [("sketch_wave", "sketch+probe"), ("sketch_dpp", "sketch+probe"), ("probe_wave", "sketch+probe"), ("scan_", None),
+            ("scatter_group", "emit"), ("group_reduce", "emit"), ("sort_rank", "sort"), ("long_presort", "sort"),
+            ("long_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
 
 
 def per_kernel(path):
@@ -53,7 +53,7 @@ def phase_sums(path, counter):
         if ph is None:
             continue
         tot[ph] += sum(vals)
-        if ph == "sketch":
+        if ph == "sketch+probe":
             steps += len(vals)
     return tot, max(steps, 1)
 
@@ -71,12 +71,16 @@ def traffic(workload, fetch_csv, write_csv, out):
     cur = {}
     if os.path.exists(out):
         cur = json.load(open(out))
+    res["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes: " + os.path.basename(fetch_csv) + ", " + os.path.basename(write_csv)
+    keep = cur.get(workload, {}).get("sketch_valu_insts")
+    if keep is not None:
+        res["sketch_valu_insts"] = keep
     cur[workload] = res
     cur["_note"] = ("bytes per launch of each phase; reads = 2 x FETCH_SIZE KiB (gfx950 tallies 128-byte requests "
                     "as 64 bytes), writes = WRITE_SIZE KiB; separate --pmc passes; 'scans' (tile and cluster scans) "
                     "are listed apart from the phases they belong to")
     json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
-    print(json.dumps(res, indent=1))
+    print(json.dumps({k: v for k, v in res.items() if not k.endswith(('_read', '_write'))}, indent=1))
 
 
 def valu(workload, sq_csv, out):
