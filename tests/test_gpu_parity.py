@@ -401,3 +401,4 @@ print("child ok", first["n_hits"], int(ring[0].counts()["ms"][5]))
         outs.append(out.decode())
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "child ok" in o, o
+
