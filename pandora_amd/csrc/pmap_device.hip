@@ -380,6 +380,8 @@ struct pmap_result {
     pmap_params_t p_prm;
     bool p_fused = false;
     uint32_t p_last = 0;
+    bool long_enabled = false;        // launch the long-segment sort kernels
+    bool long_launched = false;       // ... and the last run did
     bool serial_scans = false;        // this run replaces the chained prefix sums by one workgroup per kernel
     uint32_t n_serial_reruns = 0;     // batches that needed that so far
     uint32_t kt_recorded = 0;
@@ -779,24 +781,27 @@ static int run_pipeline(pmap_result *res) {
     // ---- sort
     if (last >= PMAP_STAGE_SORT && n_tiles) {
         kt.begin(KT_SORT);
+        // (a read has at most one minimizer per base and a minimizer at most max_cnt hits)
+        res->long_launched = res->long_enabled && (uint64_t) rd->max_len * idx->max_cnt > g_sort_long;
 #define SORT_ARGS                                                                                                     \
     &dc->n_hits, res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),      \
         res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,          \
         res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), \
-        res->s_rec.as<uint32_t>(), &dc->has_long, g_sort_long
+        res->s_rec.as<uint32_t>(), &dc->has_long, g_sort_long, res->long_launched ? 1u : 0u
         // keys are prg << 1 | strand: narrow enough to share a word with a place in the staged chunk?
         if (2ull * idx->n_prg <= (1ull << (31 - SORT_CH_BITS)) && !(prm->flags & PMAP_FLAG_SORT_WIDE))
             KLAUNCH(sort_rank_kernel<true>, dim3(res->hit_cap / 256), SORT_ARGS);
         else
             KLAUNCH(sort_rank_kernel<false>, dim3(res->hit_cap / 256), SORT_ARGS);
 #undef SORT_ARGS
-        // reads with more hits than the rank counting takes; launched only if such a read can exist (a read
-        // has at most one minimizer per base and a minimizer at most max_cnt hits)
-        if ((uint64_t) rd->max_len * idx->max_cnt > g_sort_long) {
-            KLAUNCH(long_presort_kernel, dim3(res->hit_cap / SORT_LB), dc, res->hit_cap, res->h_read.as<uint32_t>(),
+        // Reads with more hits than the rank counting takes.  Such reads are rare: the two kernels are launched
+        // only once a batch has turned out to hold one (pmap_map_wait then maps the batch again with them, and
+        // they stay on until a batch comes without such a read).
+        if (res->long_launched) {
+            KLAUNCH(long_presort_kernel, dim3(std::min(res->hit_cap / SORT_LB, 1024u)), dc, res->hit_cap, res->h_read.as<uint32_t>(),
                     res->h_key.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
                     res->long_words.as<unsigned long long>(), g_sort_long);
-            KLAUNCH(long_rank_kernel, dim3(res->hit_cap / 256), dc, res->hit_cap, res->h_read.as<uint32_t>(),
+            KLAUNCH(long_rank_kernel, dim3(std::min(res->hit_cap / 256, 2048u)), dc, res->hit_cap, res->h_read.as<uint32_t>(),
                     res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(),
                     res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
                     res->long_words.as<unsigned long long>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
@@ -964,6 +969,13 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
             continue;
         }
         res->serial_scans = false;
+        if (res->p_last >= PMAP_STAGE_SORT && hc.has_long && !res->long_launched) {
+            // a read with more hits than the rank counting sorts: once more with the long-segment kernels
+            res->long_enabled = true;
+            if ((rc = run_pipeline(res))) return rc;
+            continue;
+        }
+        res->long_enabled = hc.has_long != 0;
         n_mini = hc.n_mini;
         n_hits = hc.n_hits;
         if (n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
@@ -1156,6 +1168,13 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
         HIP_TRY(hipEventSynchronize(res->done));
         if (res->hc->fail) return pmap_fail(PMAP_EHIP, "the cluster kernels failed without a chained prefix sum");
     }
+    if (res->hc->has_long && !res->long_launched) {      // as pmap_map_wait: once more with the long-segment kernels
+        res->long_enabled = true;
+        if ((rc = run_pipeline(res))) return rc;
+        HIP_TRY(hipEventSynchronize(res->done));
+        if (res->hc->fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
+    }
+    res->long_enabled = res->hc->has_long != 0;
     const Counters &hc = *res->hc;
     counts->n_reads = rd->n_reads;
     counts->n_bases = rd->n_bases;

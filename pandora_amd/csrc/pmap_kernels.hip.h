@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
                                                         const uint32_t *__restrict__ hbounds, uint32_t n_reads,
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
-                                                        uint32_t *__restrict__ s_rec, uint32_t *__restrict__ has_long, uint32_t sort_long) {
+                                                        uint32_t *__restrict__ s_rec, uint32_t *__restrict__ has_long, uint32_t sort_long,
+                                                        uint32_t long_follows) {
     __shared__ uint32_t keys[SORT_CH];
     __shared__ uint32_t wlo[4], whi[4];
     const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
@@ -306,6 +307,16 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
         if (e - s > sort_long) {
             active = false;
             *has_long = 1u;             // every writer stores the same value
+            if (!long_follows) {
+                // The long-segment kernels are not part of this run: the host will map the batch again with
+                // them.  Until then the kernels behind this one must find a well-formed hit in every place
+                // (they index tables by its fields): the hit stays where it is, unsorted.
+                s_read[i] = r;
+                s_key[i] = key;
+                s_pos[i] = h_pos[i];
+                s_rank[i] = h_rank[i];
+                s_rec[i] = h_rec[i];
+            }
         }
     }
     // the stretch of hits this block's reads cover: from the first active thread's read to the last one's
@@ -380,11 +391,11 @@ __global__ __launch_bounds__(256) void long_presort_kernel(const Counters *__res
                                                            const uint32_t *__restrict__ h_key,
                                                            const uint32_t *__restrict__ hbounds, uint32_t n_reads,
                                                            unsigned long long *__restrict__ words, uint32_t sort_long) {
-    if (!dc->has_long) return;
+    if (!dc->has_long) return;       // the usual case: a small grid that leaves at once
     __shared__ unsigned long long w[SORT_LB];
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
-    const uint32_t b0 = blockIdx.x * SORT_LB;
-    if (b0 >= n_hits) return;
+    for (uint32_t b0 = blockIdx.x * SORT_LB; b0 < n_hits; b0 += gridDim.x * SORT_LB) {
+    __syncthreads();                 // the block before has been written out
     const uint32_t n = min(SORT_LB, n_hits - b0);
     // does a long segment touch the block?  One that is longer than a block holds the block's first or last hit
     // if it touches it at all; shorter ones (a low threshold) may lie inside: look at every hit then
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(256) void long_presort_kernel(const Counters *__res
         for (uint32_t t = threadIdx.x; t < n; t += 256) mine = mine || in_long_segment(b0 + t, h_read, hbounds, n_reads, sort_long);
         touched = __syncthreads_or(mine) != 0;
     }
-    if (!touched) return;
+    if (!touched) continue;
     const uint32_t r0 = h_read[b0];
     for (uint32_t t = threadIdx.x; t < SORT_LB; t += 256)
         w[t] = t < n ? long_word(h_read[b0 + t] - r0, h_key[b0 + t], t) : ~0ull;
@@ -413,6 +424,7 @@ __global__ __launch_bounds__(256) void long_presort_kernel(const Counters *__res
             __syncthreads();
         }
     for (uint32_t t = threadIdx.x; t < SORT_LB; t += 256) words[b0 + t] = w[t];
+    }
 }
 
 // number of words of the sorted block below `x` (the block has SORT_LB words, padded with all-ones)
@@ -435,13 +447,12 @@ __global__ __launch_bounds__(256) void long_rank_kernel(const Counters *__restri
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
                                                         uint32_t *__restrict__ s_rec, uint32_t sort_long) {
-    if (!dc->has_long) return;
+    if (!dc->has_long) return;       // the usual case: a small grid that leaves at once
     const uint32_t n_hits = clamp_count(&dc->n_hits, hit_cap);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_hits) return;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_hits; i += gridDim.x * 256) {
     const uint32_t r = h_read[i], key = h_key[i];
     const uint32_t s = hbounds[r], e = ~hbounds[n_reads + r];
-    if (e - s <= sort_long || e > n_hits) return;
+    if (e - s <= sort_long || e > n_hits) continue;
     const uint32_t own = i >> SORT_LB_BITS;
     uint32_t c = 0;
     for (uint32_t blk = s >> SORT_LB_BITS; blk <= (e - 1) >> SORT_LB_BITS; ++blk) {
@@ -455,12 +466,13 @@ __global__ __launch_bounds__(256) void long_rank_kernel(const Counters *__restri
         c += upto - first;
     }
     const uint32_t d = s + c;
-    if (d >= n_hits) return;
+    if (d >= n_hits) continue;
     s_read[d] = r;
     s_key[d] = key;
     s_pos[d] = h_pos[i];
     s_rank[d] = h_rank[i];
     s_rec[d] = h_rec[i];
+    }
 }
 
 // ---------------------------------------------------------------------------
