@@ -631,17 +631,22 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
         for (uint32_t i = gid; i < aux.n_state_words; i += gsz) aux.state[i] = 0ull;
         for (uint32_t i = gid; i < aux.n_hb; i += gsz) aux.hbounds[i] = 0xFFFFFFFFu;
     }
+    // Minimizers of a tile go through a list of {hash, position in the tile} in LDS.  Sparse sketches
+    // (w >= 8: about one position in eight) get a list of CAP = 5/8 of the positions, which makes 6 workgroups
+    // fit a compute unit (measured best for the whole pipeline: 8 leave the kernels of the batch before no
+    // room next to this one, 5 hide less latency); a tile with more minimizers than that (low-complexity
+    // sequence) takes two passes of CAP, each of which computes the tile again.  Dense sketches get a full list.
+    constexpr int CAP = WC >= 8 ? T::POS * 5 / 8 : T::POS;
     __shared__ uint32_t sW[4][T::NWD], sStart[4][T::NWD], sLen[4][T::NWD], sRead[4][T::NWD];
-    __shared__ __align__(16) uint32_t sH[4][T::POS];
-    __shared__ uint16_t sList[4][T::POS];
+    __shared__ __align__(8) uint2 sList[4][CAP];
     __shared__ uint32_t sStrand[4][64];
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * 4 + wv;
     if (g >= n_tiles) return;
     uint32_t *W = sW[wv], *mstart = sStart[wv], *mlen = sLen[wv], *wr = sRead[wv];
-    uint32_t *h = sH[wv], *strands = sStrand[wv];
-    uint16_t *list = sList[wv];
+    uint32_t *strands = sStrand[wv];
+    uint2 *list = sList[wv];
 
     const int a = WC - 1;
     const int64_t P0 = (int64_t) g * T::OUT - DPP_HALO;        // position 0 of the tile, a multiple of 16
@@ -676,6 +681,14 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     // ---- canonical hashes of the lane's NP positions (src/seq.cpp:41-47, 109-111)
     const uint32_t mask = (uint32_t) (((uint64_t) 1 << (2 * k)) - 1);
     const HashWidths hw = hash_widths(k);
+    constexpr bool LAZY_STRAND = FUSED && WC >= 8;
+    const uint64_t slot0 = (uint64_t) g * T::POS;
+    uint32_t n = 0, nent = 0, hits = 0;
+    // One pass works the minimizers of ranks [pb, pb + CAP) of the tile.  A second pass (low-complexity
+    // sequence only) computes everything again from what the tile has in LDS: nothing is to stay in
+    // registers across the lookups for its sake, and it is a second copy of the code, not a loop, for the
+    // same reason (as a loop the kernel took 77 registers instead of 48).
+    auto tile_pass = [&](const uint32_t pb) __attribute__((always_inline)) {
     const int wi = NP == 16 ? lane : lane >> 1;
     const uint32_t len = mlen[wi];
     const uint32_t j0 = P0lo + (uint32_t) NP * (uint32_t) lane - mstart[wi];   // position of the lane's first base inside its read
@@ -698,10 +711,9 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     const uint32_t ylo = revcomp16(x0), yhi = revcomp16(x1);
     uint32_t own[NP];
     uint32_t nstrand = 0;           // bit NP-1 - j: h_fwd > h_rc at position j, i.e. strand = 0
-    // Sparse sketches in fused mode: only the few minimizers that have records need their strand, and
-    // hashing their forward k-mer once more (strand = the canonical hash is the forward one) costs less
-    // than keeping two instructions per position here.
-    constexpr bool LAZY_STRAND = FUSED && WC >= 8;
+    // Sparse sketches in fused mode (LAZY_STRAND): only the few minimizers that have records need their
+    // strand, and hashing their forward k-mer once more (strand = the canonical hash is the forward one)
+    // costs less than keeping two instructions per position here.
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         uint32_t fwd;
@@ -721,9 +733,6 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
         if constexpr (!LAZY_STRAND) nstrand = __builtin_amdgcn_alignbit(nstrand, hr - hf, 31);   // nstrand << 1 | sign
         own[j] = tmin(hf, hr);
     }
-#pragma unroll
-    for (int q = 0; q < NP / 4; ++q)
-        *(uint4 *) (h + NP * lane + 4 * q) = make_uint4(own[4 * q], own[4 * q + 1], own[4 * q + 2], own[4 * q + 3]);
     if constexpr (!LAZY_STRAND) strands[lane] = ~nstrand;
 
     // ---- L[t] = minimum of the full window ending at k-mer t, 0 if that window is not inside one read;
@@ -745,7 +754,7 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     }
     window_max_regs<WC, NP>(L);
 
-    // ---- compaction in position order with ballots: list[e] = index of the e-th minimizer in the tile
+    // ---- compaction in position order: list[e] = {hash, index in the tile} of the e-th minimizer of the pass
     const bool inr = (uint32_t) (lane - DPP_HALO / NP) < (uint32_t) (T::OUT / NP);
     // every lane counts its own flags (one add-with-carry per position), a prefix sum over the lanes
     // places the lane's first minimizer
@@ -753,48 +762,59 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
 #pragma unroll
     for (int j = 0; j < NP; ++j) mine += (inr && L[j] == cmp[j]) ? 1u : 0u;
     const uint32_t upto = wave_incl_scan(mine);
-    const uint32_t n = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
+    n = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
     uint32_t o = upto - mine;
     const uint32_t laneNP = (uint32_t) NP * (uint32_t) lane;
     asm volatile("" : "+v"(o));         // keeps the sum whole: one scaling to a byte offset, not one per term
-    uint16_t *lp = list + o;
+    if (n <= (uint32_t) CAP) {          // wave-uniform; always so for dense sketches
+        uint2 *lp = list + o;
 #pragma unroll
-    for (int j = 0; j < NP; ++j)
-        if (inr && L[j] == cmp[j]) *lp++ = (uint16_t) (laneNP | (uint32_t) j);
+        for (int j = 0; j < NP; ++j)
+            if (inr && L[j] == cmp[j]) *lp++ = make_uint2(cmp[j], laneNP | (uint32_t) j);
+    } else {
+        uint32_t r = o - pb;            // place in this pass; wraps for minimizers of earlier passes
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (inr && L[j] == cmp[j]) {
+                if (r < (uint32_t) CAP) list[r] = make_uint2(cmp[j], laneNP | (uint32_t) j);
+                ++r;
+            }
+    }
     wave_lds_sync();
+    const uint32_t np = n - pb < (uint32_t) CAP ? n - pb : (uint32_t) CAP;     // minimizers of this pass
 
-    const uint64_t slot0 = (uint64_t) g * T::POS;
-    uint32_t nent = 0, hits = 0;
     if constexpr (!FUSED) {
-        for (uint32_t base = 0; base < n; base += 64) {     // n is wave-uniform
+        for (uint32_t base = 0; base < np; base += 64) {     // np is wave-uniform
             const uint32_t e = base + lane;
-            if (e < n) {
-                const uint32_t i = list[e], wj = i >> 4;
+            if (e < np) {
+                const uint2 le = list[e];
+                const uint32_t i = le.y, wj = i >> 4;
                 // strand of position j of a lane: bit NP-1 - j of the lane's word; moved to bit 31
                 const uint32_t st = strands[i / NP] << (32 - NP + (i & (NP - 1)));
-                mkmer[slot0 + e] = (uint64_t) h[i];
-                ents[2 * (slot0 + e)] = make_uint4(wr[wj], (P0lo + i - mstart[wj]) | (st & 0x80000000u), 0, 0);
+                mkmer[slot0 + pb + e] = (uint64_t) le.x;
+                ents[2 * (slot0 + pb + e)] = make_uint4(wr[wj], (P0lo + i - mstart[wj]) | (st & 0x80000000u), 0, 0);
             }
         }
     } else {
         // ---- presence filter for every minimizer: up to 4 rounds of 64 at a time, their loads in
         // flight together; what passes stays in the list (compacted in place, position order kept)
         uint32_t n2 = 0;
-        for (uint32_t base = 0; base < n; base += 256) {
-            uint32_t idx[4], fw[4], fb[4], fb2[4];
+        for (uint32_t base = 0; base < np; base += 256) {
+            uint2 le[4];
+            uint32_t fw[4], fb[4], fb2[4];
             const uint32_t fsh = (32 - (fbits & 0xFFu)) & 31u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                idx[r] = 0;
+                le[r] = make_uint2(0, 0);
                 fw[r] = 0;          // lanes past the end pass nothing
                 fb[r] = fb2[r] = 0;
-                if (base + 64 * r < n) {
+                if (base + 64 * r < np) {
                     const uint32_t e = base + 64 * r + lane;
-                    if (e < n) {
-                        idx[r] = list[e];
+                    if (e < np) {
+                        le[r] = list[e];
                         fw[r] = 0xFFFFFFFFu;
                         if (fbits) {
-                            const uint32_t hm = pmap_key_mix((uint64_t) h[idx[r]]);
+                            const uint32_t hm = pmap_key_mix((uint64_t) le[r].x);
                             fb[r] = hm >> fsh;                                  // pmap_filter_word / pmap_filter_mask
                             if (fbits & PMAP_FILTER_TWO) fb2[r] = hm >> 3;
                             fw[r] = filt[fb[r] >> 5];
@@ -804,15 +824,14 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (base + 64 * r < n) {
+                if (base + 64 * r < np) {
                     // bit fb & 31 of the word and, with two bits per key, bit fb2 & 31 as well
                     uint32_t t = __builtin_amdgcn_ubfe(fw[r], fb[r], 1u);
                     if (fbits & PMAP_FILTER_TWO) t &= fw[r] >> (fb2[r] & 31u);
                     const bool pass = t != 0;
                     const unsigned long long b = ballot64(pass);
                     if (pass)
-                        list[n2 + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0))] =
-                            (uint16_t) idx[r];
+                        list[n2 + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0))] = le[r];
                     n2 += __popcll(b);
                 }
         }
@@ -823,7 +842,8 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             uint32_t cnt = 0, off = 0, ps = 0, rd = 0;
             uint4 first = make_uint4(0, 0, 0, 0);
             if (e < n2) {
-                const uint32_t i = list[e], wj = i >> 4, hv = h[i];
+                const uint2 le = list[e];
+                const uint32_t i = le.y, wj = i >> 4, hv = le.x;
                 index_lookup(slots, log2cap, nullptr, 0u, (uint64_t) hv, &cnt, &off, &first);
                 uint32_t st;
                 if constexpr (LAZY_STRAND) {
@@ -846,6 +866,15 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             }
             nent += __popcll(b);
             hits += cnt;
+        }
+    }
+    };
+    tile_pass(0u);
+    if constexpr (CAP < T::POS) {
+        static_assert(2 * CAP >= T::POS, "two passes cover a tile");
+        if (n > (uint32_t) CAP) {
+            wave_lds_sync();            // the second pass writes the list again
+            tile_pass((uint32_t) CAP);
         }
     }
     if (FUSED) hits = wave_sum(hits);

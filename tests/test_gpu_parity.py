@@ -51,6 +51,22 @@ def test_low_complexity_ties(gpu):
         compare_batch(si, bases, off, w, k, 50, api.fraction(0.01, k), min_cluster_size=1)
 
 
+def test_tiles_with_more_minimizers_than_one_pass(gpu):
+    """Long low-complexity stretches: nearly every position of a tile is a minimizer.  The sparse sketch
+    kernels (w >= 8) keep a tile's minimizers in a list shorter than the tile and take a second pass for
+    such tiles; stretches start and end inside tiles, so both passes of a tile hold minimizers."""
+    rng = np.random.default_rng(15)
+    rnd = lambda n: bytes(synth.random_dna(n, rng))
+    reads = [b"A" * 3000, b"AC" * 2500, rnd(700) + b"A" * 1700 + rnd(900), rnd(300) + b"GT" * 400 + rnd(1000) + b"C" * 2200,
+             b"ACG" * 1500, rnd(2500), b"T" * 641 + rnd(100) + b"T" * 1300, (b"A" * 20 + b"C") * 150]
+    loci = [np.frombuffer(r, np.uint8).copy() for r in (reads[0][:300], reads[1][:300], reads[2][500:1000], reads[5][:800])]
+    for w, k in [(14, 15), (8, 8), (16, 15), (9, 5), (14, 11)]:
+        si = synth.build_index(loci, w, k)
+        bases, off = O.pack_reads(reads)
+        cn, _ = compare_batch(si, bases, off, w, k, 50, api.fraction(0.01, k), min_cluster_size=1)
+        assert cn["n_minimizers"] > 9000
+
+
 def test_edge_reads(gpu):
     """Lengths around w+k-1, non-ACGT letters, lower case, raw 0..3 bytes, empty reads."""
     rng = np.random.default_rng(6)
