@@ -189,7 +189,7 @@ typedef struct {
     uint8_t fwd;
 } cl_t;
 
-static const orc_index_t *g_idx; /* comparator context (qsort has no user pointer) */
+static __thread const orc_index_t *g_idx; /* comparator context (qsort has no user pointer); per thread: callers may run in parallel */
 
 static int rec_path_cmp(uint32_t ra, uint32_t rb) {
     const orc_index_t *x = g_idx;
