@@ -285,7 +285,9 @@ struct Counters {
     unsigned long long n_kept;    // clusters kept
     uint32_t fail;                // a chained prefix sum gave up waiting
     uint32_t has_long;            // some read has more hits than the rank-counting sort takes: the long-segment kernels have work
-    uint32_t pad[4];
+    uint32_t dense_marks;         // sum of tile_cnt.w: tiles with more minimizers than the sketch kernel's list holds (1 each: left
+                                  // out, the overflow kernel has work; 2 each: done by it)
+    uint32_t pad[3];
 };
 static_assert(sizeof(Counters) == 64, "Counters is the head of the state block");
 
@@ -382,6 +384,8 @@ struct pmap_result {
     uint32_t p_last = 0;
     bool long_enabled = false;        // launch the long-segment sort kernels
     bool long_launched = false;       // ... and the last run did
+    bool dense_enabled = false;       // launch the sketch kernel for tiles with more minimizers than the usual one's list holds
+    bool dense_launched = false;
     bool serial_scans = false;        // this run replaces the chained prefix sums by one workgroup per kernel
     uint32_t n_serial_reruns = 0;     // batches that needed that so far
     uint32_t kt_recorded = 0;
@@ -602,6 +606,14 @@ static thread_local KTimer *g_kt = nullptr;
         else kernel<<<grid, dim3(block), 0, g_cur>>>(__VA_ARGS__);                                          \
     } while (0)
 // (not written in terms of KLAUNCH_B: a second expansion would split template arguments at their commas)
+// LDS = dynamic LDS bytes on top of the kernel's own
+#define KLAUNCH_L(kernel, grid, LDS, ...)                                                                 \
+    do {                                                                                                  \
+        hipEvent_t s_ = nullptr, e_ = nullptr;                                                            \
+        if (g_kt) g_kt->events(&s_, &e_);                                                                 \
+        if (s_ || e_) hipExtLaunchKernelGGL(kernel, grid, dim3(256), LDS, g_cur, s_, e_, 0, __VA_ARGS__);  \
+        else kernel<<<grid, dim3(256), LDS, g_cur>>>(__VA_ARGS__);                                        \
+    } while (0)
 #define KLAUNCH(kernel, grid, ...)                                                                        \
     do {                                                                                                  \
         hipEvent_t s_ = nullptr, e_ = nullptr;                                                            \
@@ -646,6 +658,9 @@ static uint32_t round_up(uint64_t v, uint32_t m) {
 
 // enqueues the whole pipeline once with the current capacities; the counters arrive in res->hc
 // when res->done has happened
+// extra dynamic LDS per workgroup of the register-window sketch kernels: lowers how many of them share a
+// compute unit (6 with none; for experiments)
+static unsigned g_sketch_pad = getenv("PMAP_SKETCH_LDS_PAD") ? (unsigned) std::max(0, atoi(getenv("PMAP_SKETCH_LDS_PAD"))) : 0;
 static int run_pipeline(pmap_result *res) {
     int rc;
     const pmap_index *idx = res->p_idx;
@@ -693,11 +708,15 @@ static int run_pipeline(pmap_result *res) {
 
     // ---- sketch (+ probe when fused)
     if (n_tiles) {
+        res->dense_launched = res->dense_enabled;
         kt.begin(KT_SKETCH);
 #define SKETCH_ARGS                                                                                                   \
     rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, od.slots, idx->log2cap,                 \
         od.filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>(), \
         aux
+#define SKETCH_ARGS_NOAUX                                                                                             \
+    rd->words.as<uint2>(), rd->rmeta.as<uint2>(), rd->n_words, n_tiles, w, k, od.slots, idx->log2cap,                 \
+        od.filter, idx->filter_bits, res->mkmer.as<uint64_t>(), res->ents.as<uint4>(), res->tile_cnt.as<uint4>()
 #define SKETCH_LAUNCH(HT, FUSED, WC)                                                                                  \
     KLAUNCH(HIP_KERNEL_NAME(sketch_wave_kernel<HT, FUSED, WC>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
         // w = 14 (the default of pandora map) and w = 1 (dense sketches) have their own instantiations
@@ -709,7 +728,13 @@ static int run_pipeline(pmap_result *res) {
     } while (0)
         // k <= 15 with w <= 16: windows in registers (sketch_dpp_kernel); the default w = 14, k = 15 at compile time
 #define SKETCH_DPP(FUSED, WC, KC, NP)                                                                                 \
-    KLAUNCH(HIP_KERNEL_NAME(sketch_dpp_kernel<FUSED, WC, KC, NP>), dim3((n_tiles + 3) / 4), SKETCH_ARGS)
+    do {                                                                                                              \
+        KLAUNCH_L(HIP_KERNEL_NAME(sketch_dpp_kernel<FUSED, WC, KC, NP>), dim3((n_tiles + 3) / 4),                     \
+                  (DppList<WC, NP>::BYTES + g_sketch_pad), SKETCH_ARGS);                                              \
+        if (res->dense_launched && DppList<WC, NP>::CAP < DppTile<NP>::POS)                                           \
+            KLAUNCH_L(HIP_KERNEL_NAME(sketch_dpp_overflow_kernel<FUSED, WC, KC, NP>),                                 \
+                      dim3(std::min((n_tiles + 255) / 256, 1024u)), (4u * DppTile<NP>::POS * 8u), SKETCH_ARGS_NOAUX); \
+    } while (0)
 #define SKETCH_DPP_NP(NP)                                                                                             \
     do {                                                                                                              \
         if (fused && k == 15) SKETCH_DPP(true, 14, 15, NP);                                                           \
@@ -746,6 +771,7 @@ static int run_pipeline(pmap_result *res) {
 #undef SKETCH_DISPATCH
 #undef SKETCH_LAUNCH
 #undef SKETCH_ARGS
+#undef SKETCH_ARGS_NOAUX
         kt.end(KT_SKETCH);
         HIP_TRY(hipGetLastError());
     }
@@ -976,6 +1002,15 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
             continue;
         }
         res->long_enabled = hc.has_long != 0;
+        if (hc.dense_marks && !res->dense_launched) {
+            // a tile with more minimizers than the sketch kernel's list holds (low-complexity sequence) was left
+            // out: once more with the kernel that takes such tiles behind it; it stays on until a batch comes
+            // without such a tile
+            res->dense_enabled = true;
+            if ((rc = run_pipeline(res))) return rc;
+            continue;
+        }
+        res->dense_enabled = hc.dense_marks != 0;
         n_mini = hc.n_mini;
         n_hits = hc.n_hits;
         if (n_hits >= 0xFFFFFF00ull) return pmap_fail(PMAP_ELIMIT, "more than 2^32-257 hits in one batch");
@@ -1158,22 +1193,32 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     res->p_prm.profile = 0;
     res->p_fused = true;
     res->p_last = PMAP_STAGE_CLUSTER;
-    if ((rc = run_pipeline(res))) return rc;
-    HIP_TRY(hipEventSynchronize(res->done));
-    if (res->hc->fail) {                      // as pmap_map_wait: once more without a chain between workgroups
-        res->serial_scans = true;
-        rc = run_pipeline(res);
+    // as pmap_map_wait: the batch is mapped again without a chain between workgroups when a chained prefix sum
+    // gave up, with the kernel for tiles full of minimizers when the usual one left a tile out, with the
+    // long-segment sort kernels when a read had more hits than the rank counting takes
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = run_pipeline(res))) { res->serial_scans = false; return rc; }
+        HIP_TRY(hipEventSynchronize(res->done));
+        if (res->hc->fail) {
+            if (res->serial_scans) {
+                res->serial_scans = false;
+                return pmap_fail(PMAP_EHIP, "the cluster kernels failed without a chained prefix sum");
+            }
+            res->serial_scans = true;
+            continue;
+        }
         res->serial_scans = false;
-        if (rc) return rc;
-        HIP_TRY(hipEventSynchronize(res->done));
-        if (res->hc->fail) return pmap_fail(PMAP_EHIP, "the cluster kernels failed without a chained prefix sum");
+        if (res->hc->dense_marks && !res->dense_launched) {
+            res->dense_enabled = true;
+            continue;
+        }
+        if (res->hc->has_long && !res->long_launched) {
+            res->long_enabled = true;
+            continue;
+        }
+        break;
     }
-    if (res->hc->has_long && !res->long_launched) {      // as pmap_map_wait: once more with the long-segment kernels
-        res->long_enabled = true;
-        if ((rc = run_pipeline(res))) return rc;
-        HIP_TRY(hipEventSynchronize(res->done));
-        if (res->hc->fail) return pmap_fail(PMAP_EHIP, "a chained prefix sum timed out waiting for an earlier block");
-    }
+    res->dense_enabled = res->hc->dense_marks != 0;
     res->long_enabled = res->hc->has_long != 0;
     const Counters &hc = *res->hc;
     counts->n_reads = rd->n_reads;

@@ -53,23 +53,24 @@ __global__ __launch_bounds__(256) void probe_wave_kernel(const uint64_t *__restr
     if (lane == 0) ((uint32_t *) (tile_cnt + g))[2] = mine;
 }
 
-// group_sum[G] = {minimizers, entries, hits, 0} of the GROUP_TILES tiles of group G: one wavefront per group
+// group_sum[G] = {minimizers, entries, hits, marks} of the GROUP_TILES tiles of group G (marks: tile_cnt.w, set for
+// tiles with more minimizers than the sketch kernel's list holds): one wavefront per group
 __global__ __launch_bounds__(256) void group_reduce_kernel(const uint4 *__restrict__ tile_cnt, uint32_t n_tiles,
                                                            uint4 *__restrict__ group_sum) {
     const uint32_t lane = threadIdx.x & 63, G = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t t0 = G * GROUP_TILES;
     if (t0 >= n_tiles) return;
-    uint32_t x = 0, y = 0, z = 0;
+    uint32_t x = 0, y = 0, z = 0, v = 0;
 #pragma unroll
     for (uint32_t i = 0; i < GROUP_TILES / 64; ++i) {
         const uint32_t t = t0 + i * 64 + lane;
         if (t < n_tiles) {
             const uint4 c = tile_cnt[t];
-            x += c.x; y += c.y; z += c.z;
+            x += c.x; y += c.y; z += c.z; v += c.w;
         }
     }
-    x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
-    if (lane == 0) group_sum[G] = make_uint4(x, y, z, 0);
+    x = wave_sum(x); y = wave_sum(y); z = wave_sum(z); v = wave_sum(v);
+    if (lane == 0) group_sum[G] = make_uint4(x, y, z, v);
 }
 
 // Hit emission (MinimizerHit ctor, src/minihit.cpp:14-22).  A wavefront takes SCATTER_TILES tiles.
@@ -121,18 +122,21 @@ __global__ __launch_bounds__(256) void scatter_group_kernel(
     if (t0 + SCATTER_TILES >= n_tiles) {
         // last wavefront: batch totals, in 64 bits, for the kernels that follow and for the host
         const unsigned long long h = wave_sum64(before64 + c.z);
-        unsigned long long m = 0, en = 0;
+        unsigned long long m = 0, en = 0, mk = 0;
         for (uint32_t i = lane; i <= G; i += 64) {
             const uint4 gs = group_sum[i];
             m += gs.x;
             en += gs.y;
+            mk += gs.w;
         }
         m = wave_sum64(m);
         en = wave_sum64(en);
+        mk = wave_sum64(mk);
         if (lane == 0) {
             dc->n_hits = h;
             dc->n_mini = m;
             dc->n_ent = en;
+            dc->dense_marks = (uint32_t) (mk < 0xFFFFFFFFull ? mk : 0xFFFFFFFFull);
         }
     }
     if (!emit || E == 0) return;

@@ -13,6 +13,8 @@
 #ifndef PMAP_SKETCH_HIP_H
 #define PMAP_SKETCH_HIP_H
 
+#include <type_traits>
+
 static const int SK_NQ = 2;                        // quads per lane
 static const int WAVE_Q = 64 * SK_NQ;              // quads per wavefront window
 static const int WAVE_POS = 4 * WAVE_Q;            // 512 positions, also the slot stride per wavefront
@@ -556,6 +558,22 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
 // wavefronts per SIMD.
 static const int DPP_HALO = 16;
 static const int DPP_MAX_W = 16;
+// Minimizers of a tile go through a list of {hash, position in the tile} in LDS, one list per wavefront.
+// Sparse sketches (w >= 8: about one position in eight) get a list of CAP = 5/8 of the tile's positions,
+// which makes 6 workgroups fit a compute unit (measured best for the whole pipeline: 8 leave the kernels
+// of the batch before no room next to this one, 5 hide less latency); a tile with more minimizers than
+// that (low-complexity sequence) is left to sketch_dpp_overflow_kernel, which the host adds once a batch
+// had such a tile.  Dense sketches get a full list.
+// The lists are DYNAMIC LDS, sized by the launch: the compiler pads a kernel's register allocation up
+// to what the occupancy allowed by its STATIC LDS leaves room for (24 KB of static LDS: 6 waves per SIMD,
+// 73 registers allocated for the 50 in use), and those registers are then missing for the kernels
+// of the batch before, which run next to this one (0.225 instead of 0.19 ms per step of the pipeline).
+template <int WC, int NP>
+struct DppList {
+    static const int CAP = WC >= 8 ? 64 * NP * 5 / 8 : 64 * NP;
+    static const unsigned BYTES = 4u * CAP * 8u;          // 4 wavefronts per workgroup, 8 bytes per entry
+};
+
 template <int NP>
 struct DppTile {
     static const int POS = 64 * NP;                 // positions of a tile = slot stride of its outputs
@@ -612,42 +630,18 @@ __device__ __forceinline__ void window_max_regs(uint32_t (&v)[N]) {
     }
 }
 
-// Same arguments and outputs as sketch_wave_kernel<uint32_t, FUSED, WC>; a tile has
-// DppTile<NP>::OUT output positions and its outputs sit at a slot stride of DppTile<NP>::POS.
-// KC > 0 fixes k at compile time.
-template <bool FUSED, int WC, int KC, int NP>
-__global__ __launch_bounds__(256) void sketch_dpp_kernel(
-    const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
-    uint32_t w_arg, uint32_t k_arg, const PmapSlot *__restrict__ slots, uint32_t log2cap,
-    const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
-    uint4 *__restrict__ tile_cnt, SketchAux aux) {
-    static_assert(WC >= 1 && WC <= DPP_MAX_W && WC - 1 <= DPP_HALO, "window steps must stay within the neighbouring lane");
-    static_assert(NP == 8 || NP == 16, "a lane starts at a word or half-word boundary");
+// One tile of sketch_dpp_kernel, by one wavefront: tile g of the batch, its minimizers through `list` (CAP
+// entries of LDS).  Returns false, with nothing written, when the tile has more than CAP minimizers;
+// otherwise writes the tile's outputs and tile_cnt[g] = {minimizers, entries, hits, mark}.
+// W, mstart, mlen, wr: the wavefront's DppTile<NP>::NWD words of LDS each; strands: 64 words.
+template <bool FUSED, int WC, int KC, int NP, int CAP>
+__device__ __forceinline__ bool sketch_dpp_tile(
+    const uint32_t g, const int lane, uint32_t *W, uint32_t *mstart, uint32_t *mlen, uint32_t *wr, uint32_t *strands,
+    uint2 *list, const uint32_t mark, const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words,
+    uint32_t k_arg, const PmapSlot *__restrict__ slots, uint32_t log2cap, const uint32_t *__restrict__ filt,
+    uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents, uint4 *__restrict__ tile_cnt) {
     typedef DppTile<NP> T;
-    (void) w_arg;
     const uint32_t w = WC, k = KC ? (uint32_t) KC : k_arg;
-    if (blockIdx.x * 256u < (aux.n_state_words > aux.n_hb ? aux.n_state_words : aux.n_hb)) {
-        const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-        for (uint32_t i = gid; i < aux.n_state_words; i += gsz) aux.state[i] = 0ull;
-        for (uint32_t i = gid; i < aux.n_hb; i += gsz) aux.hbounds[i] = 0xFFFFFFFFu;
-    }
-    // Minimizers of a tile go through a list of {hash, position in the tile} in LDS.  Sparse sketches
-    // (w >= 8: about one position in eight) get a list of CAP = 5/8 of the positions, which makes 6 workgroups
-    // fit a compute unit (measured best for the whole pipeline: 8 leave the kernels of the batch before no
-    // room next to this one, 5 hide less latency); a tile with more minimizers than that (low-complexity
-    // sequence) takes two passes of CAP, each of which computes the tile again.  Dense sketches get a full list.
-    constexpr int CAP = WC >= 8 ? T::POS * 5 / 8 : T::POS;
-    __shared__ uint32_t sW[4][T::NWD], sStart[4][T::NWD], sLen[4][T::NWD], sRead[4][T::NWD];
-    __shared__ __align__(8) uint2 sList[4][CAP];
-    __shared__ uint32_t sStrand[4][64];
-
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const uint32_t g = blockIdx.x * 4 + wv;
-    if (g >= n_tiles) return;
-    uint32_t *W = sW[wv], *mstart = sStart[wv], *mlen = sLen[wv], *wr = sRead[wv];
-    uint32_t *strands = sStrand[wv];
-    uint2 *list = sList[wv];
-
     const int a = WC - 1;
     const int64_t P0 = (int64_t) g * T::OUT - DPP_HALO;        // position 0 of the tile, a multiple of 16
     const int32_t wbase = (int32_t) (P0 >> 4);                  // -1 for g = 0
@@ -684,11 +678,6 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     constexpr bool LAZY_STRAND = FUSED && WC >= 8;
     const uint64_t slot0 = (uint64_t) g * T::POS;
     uint32_t n = 0, nent = 0, hits = 0;
-    // One pass works the minimizers of ranks [pb, pb + CAP) of the tile.  A second pass (low-complexity
-    // sequence only) computes everything again from what the tile has in LDS: nothing is to stay in
-    // registers across the lookups for its sake, and it is a second copy of the code, not a loop, for the
-    // same reason (as a loop the kernel took 77 registers instead of 48).
-    auto tile_pass = [&](const uint32_t pb) __attribute__((always_inline)) {
     const int wi = NP == 16 ? lane : lane >> 1;
     const uint32_t len = mlen[wi];
     const uint32_t j0 = P0lo + (uint32_t) NP * (uint32_t) lane - mstart[wi];   // position of the lane's first base inside its read
@@ -766,22 +755,15 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
     uint32_t o = upto - mine;
     const uint32_t laneNP = (uint32_t) NP * (uint32_t) lane;
     asm volatile("" : "+v"(o));         // keeps the sum whole: one scaling to a byte offset, not one per term
-    if (n <= (uint32_t) CAP) {          // wave-uniform; always so for dense sketches
+    if (n > (uint32_t) CAP) return false;       // wave-uniform; never so for dense sketches
+    {
         uint2 *lp = list + o;
 #pragma unroll
         for (int j = 0; j < NP; ++j)
             if (inr && L[j] == cmp[j]) *lp++ = make_uint2(cmp[j], laneNP | (uint32_t) j);
-    } else {
-        uint32_t r = o - pb;            // place in this pass; wraps for minimizers of earlier passes
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            if (inr && L[j] == cmp[j]) {
-                if (r < (uint32_t) CAP) list[r] = make_uint2(cmp[j], laneNP | (uint32_t) j);
-                ++r;
-            }
     }
     wave_lds_sync();
-    const uint32_t np = n - pb < (uint32_t) CAP ? n - pb : (uint32_t) CAP;     // minimizers of this pass
+    const uint32_t np = n;
 
     if constexpr (!FUSED) {
         for (uint32_t base = 0; base < np; base += 64) {     // np is wave-uniform
@@ -791,8 +773,8 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
                 const uint32_t i = le.y, wj = i >> 4;
                 // strand of position j of a lane: bit NP-1 - j of the lane's word; moved to bit 31
                 const uint32_t st = strands[i / NP] << (32 - NP + (i & (NP - 1)));
-                mkmer[slot0 + pb + e] = (uint64_t) le.x;
-                ents[2 * (slot0 + pb + e)] = make_uint4(wr[wj], (P0lo + i - mstart[wj]) | (st & 0x80000000u), 0, 0);
+                mkmer[slot0 + e] = (uint64_t) le.x;
+                ents[2 * (slot0 + e)] = make_uint4(wr[wj], (P0lo + i - mstart[wj]) | (st & 0x80000000u), 0, 0);
             }
         }
     } else {
@@ -868,18 +850,73 @@ __global__ __launch_bounds__(256) void sketch_dpp_kernel(
             hits += cnt;
         }
     }
-    };
-    tile_pass(0u);
-    if constexpr (CAP < T::POS) {
-        static_assert(2 * CAP >= T::POS, "two passes cover a tile");
-        if (n > (uint32_t) CAP) {
-            wave_lds_sync();            // the second pass writes the list again
-            tile_pass((uint32_t) CAP);
-        }
-    }
     if (FUSED) hits = wave_sum(hits);
     else nent = n;
-    if (lane == 0) tile_cnt[g] = make_uint4(n, nent, hits, 0);
+    if (lane == 0) tile_cnt[g] = make_uint4(n, nent, hits, mark);
+    return true;
+}
+
+
+// Same arguments and outputs as sketch_wave_kernel<uint32_t, FUSED, WC>; a tile has
+// DppTile<NP>::OUT output positions and its outputs sit at a slot stride of DppTile<NP>::POS.
+// KC > 0 fixes k at compile time.  Dynamic LDS: DppList<WC, NP>::BYTES.
+// A tile with more minimizers than its list holds gets tile_cnt = {0, 0, 0, 1} and nothing else: the
+// batch totals then tell the host to map the batch again with sketch_dpp_overflow_kernel behind this one.
+template <bool FUSED, int WC, int KC, int NP>
+__global__ __launch_bounds__(256) void sketch_dpp_kernel(
+    const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
+    uint32_t w_arg, uint32_t k_arg, const PmapSlot *__restrict__ slots, uint32_t log2cap,
+    const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
+    uint4 *__restrict__ tile_cnt, SketchAux aux) {
+    static_assert(WC >= 1 && WC <= DPP_MAX_W && WC - 1 <= DPP_HALO, "window steps must stay within the neighbouring lane");
+    static_assert(NP == 8 || NP == 16, "a lane starts at a word or half-word boundary");
+    typedef DppTile<NP> T;
+    (void) w_arg;
+    if (blockIdx.x * 256u < (aux.n_state_words > aux.n_hb ? aux.n_state_words : aux.n_hb)) {
+        const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+        for (uint32_t i = gid; i < aux.n_state_words; i += gsz) aux.state[i] = 0ull;
+        for (uint32_t i = gid; i < aux.n_hb; i += gsz) aux.hbounds[i] = 0xFFFFFFFFu;
+    }
+    constexpr int CAP = DppList<WC, NP>::CAP;
+    __shared__ uint32_t sW[4][T::NWD], sStart[4][T::NWD], sLen[4][T::NWD], sRead[4][T::NWD];
+    extern __shared__ __align__(8) unsigned char sketch_dyn_lds[];      // DppList<WC, NP>::BYTES, from the launch
+    __shared__ uint32_t sStrand[4][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint32_t g = blockIdx.x * 4 + wv;
+    if (g >= n_tiles) return;
+    const bool done = sketch_dpp_tile<FUSED, WC, KC, NP, CAP>(
+        g, lane, sW[wv], sStart[wv], sLen[wv], sRead[wv], sStrand[wv], (uint2 *) sketch_dyn_lds + wv * CAP, 0u, words, rmeta,
+        n_words, k_arg, slots, log2cap, filt, fbits, mkmer, ents, tile_cnt);
+    if (!done && lane == 0) tile_cnt[g] = make_uint4(0, 0, 0, 1);
+}
+
+// The tiles sketch_dpp_kernel left out (tile_cnt[g].w == 1), with a list as long as the tile; marks them
+// with tile_cnt[g].w = 2, so that the batch totals still tell that the batch had such tiles.  Any grid:
+// a wavefront looks at 64 tiles at a time.  Dynamic LDS: 4 * DppTile<NP>::POS * 8 bytes.
+template <bool FUSED, int WC, int KC, int NP>
+__global__ __launch_bounds__(256) void sketch_dpp_overflow_kernel(
+    const uint2 *__restrict__ words, const uint2 *__restrict__ rmeta, uint32_t n_words, uint32_t n_tiles,
+    uint32_t w_arg, uint32_t k_arg, const PmapSlot *__restrict__ slots, uint32_t log2cap,
+    const uint32_t *__restrict__ filt, uint32_t fbits, uint64_t *__restrict__ mkmer, uint4 *__restrict__ ents,
+    uint4 *__restrict__ tile_cnt) {
+    typedef DppTile<NP> T;
+    (void) w_arg;
+    __shared__ uint32_t sW[4][T::NWD], sStart[4][T::NWD], sLen[4][T::NWD], sRead[4][T::NWD];
+    extern __shared__ __align__(8) unsigned char sketch_dyn_lds[];
+    __shared__ uint32_t sStrand[4][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    for (uint64_t t0 = ((uint64_t) blockIdx.x * 4 + wv) * 64; t0 < n_tiles; t0 += (uint64_t) gridDim.x * 4 * 64) {
+        const uint64_t t = t0 + lane;
+        unsigned long long todo = ballot64(t < n_tiles && tile_cnt[t].w == 1u);
+        while (todo) {                  // wave-uniform
+            const uint32_t g = (uint32_t) t0 + (uint32_t) __builtin_ctzll(todo);
+            todo &= todo - 1;
+            sketch_dpp_tile<FUSED, WC, KC, NP, T::POS>(g, lane, sW[wv], sStart[wv], sLen[wv], sRead[wv], sStrand[wv],
+                                                      (uint2 *) sketch_dyn_lds + wv * T::POS, 2u, words, rmeta, n_words,
+                                                      k_arg, slots, log2cap, filt, fbits, mkmer, ents, tile_cnt);
+            wave_lds_sync();            // the next tile writes the same LDS
+        }
+    }
 }
 
 #endif
