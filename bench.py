@@ -367,8 +367,10 @@ def main():
                 if dom == "sketch+probe" and rec.get("sketch_valu_insts") and args.scale == 1.0:
                     valu = {"wave_insts_per_launch": rec["sketch_valu_insts"], "peak_insts_per_s": VALU_PEAK_WAVE_INSTS,
                             "frac": rec["sketch_valu_insts"] / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS,
-                            "note": "VALU issue roofline at 2.4 GHz, the kernel's binding limit; instruction count "
-                                    "from the committed PMC pass, duration from this run"}
+                            "note": "VALU issue roofline at the nominal 2.4 GHz (256 CUs x 4 SIMDs, 4 cycles per wavefront "
+                                    "instruction), the kernel's binding limit; instruction count from the committed PMC "
+                                    "pass, duration from this run; frac_alone (the kernel with the machine to itself) "
+                                    "comes out a few percent above 1 when the engine clock is above nominal"}
             except Exception:
                 traffic, valu = None, None
         roofline = {"bound": "hbm", "limited_by": "valu" if dom == "sketch+probe" else "latency",
