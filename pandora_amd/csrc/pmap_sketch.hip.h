@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(
 // The tile starts 16 positions before its first output position (a multiple of 16: lane l's
 // bases start at a word or half-word boundary of the packed stream) and has 16 halo positions at
 // the end.  NP = 16 halves what is paid per tile (halo, set-up) and fills the 64 lanes of the
-// lookup rounds better (about 132 minimizers in 3 rounds instead of 66 in 2) at 5 instead of 8
+// lookup rounds better (about 132 minimizers in 3 rounds instead of 66 in 2) at 6 instead of 8
 // wavefronts per SIMD.
 static const int DPP_HALO = 16;
 static const int DPP_MAX_W = 16;
