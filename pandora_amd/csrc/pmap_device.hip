@@ -680,7 +680,7 @@ static int run_pipeline(pmap_result *res) {
     const uint32_t n_tiles = res->n_tiles;
     // state block: counters + one 8-byte word per block of each chained prefix sum
     res->n_ablk = res->hit_cap / CUT_BLOCK;
-    res->n_bblk = res->cl_cap / KEEP_BLOCK;
+    res->n_bblk = (res->cl_cap + KEEP_BLOCK - 1) / KEEP_BLOCK;        // (the kernel guards by the capacity itself)
     const size_t state_bytes =
         (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
     if ((rc = res->state.ensure(state_bytes))) return rc;
@@ -1143,7 +1143,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
         return pmap_fail(PMAP_EINVAL, "null output buffer");
     // capacities as the kernels' grids want them: whole blocks of the cluster kernels
     const uint32_t hit_cap = (uint32_t) std::min<uint64_t>(out->hit_cap / CUT_BLOCK * (uint64_t) CUT_BLOCK, NA_MAX_HITS);
-    const uint32_t cl_cap = (uint32_t) std::min<uint64_t>(out->cluster_cap / KEEP_BLOCK * (uint64_t) KEEP_BLOCK, NA_MAX_CLUSTERS);
+    const uint32_t cl_cap = (uint32_t) std::min<uint64_t>(out->cluster_cap / 1024u * (uint64_t) 1024u, NA_MAX_CLUSTERS);   // as documented: multiples of 1024
     if (hit_cap == 0 || cl_cap == 0)
         return pmap_fail(PMAP_EINVAL, "output buffers must hold at least 8192 hits and 1024 clusters");
     uint32_t out_pos = 0, stride = 0;

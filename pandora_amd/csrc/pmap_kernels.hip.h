@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void read_meta_kernel(const uint32_t *__restri
 // The wait is bounded and reports through *fail (no hang if the dispatch order ever differs).
 // Called by every thread of the block; lds2 = two words of LDS.
 static const uint32_t CHAIN_SPIN_LIMIT = 1u << 18;
-static const int CHAIN_SLABS = 8;     // one look-back round reads 8 x 64 predecessors, all loads in flight together
+static const int CHAIN_SLABS = 2;     // one look-back round reads 2 x 64 predecessors, both loads in flight together
 
 __device__ __forceinline__ uint32_t chained_scan(unsigned long long *gran, uint32_t b, uint32_t total,
                                                  uint32_t *fail, uint32_t *lds2, uint32_t spin_limit) {
@@ -553,11 +553,11 @@ __global__ __launch_bounds__(CUT_THREADS) void cluster_cut_kernel(Counters *__re
     }
 }
 
-// One thread per cluster, 2 rounds of 512 per block: size threshold (src/utils.cpp:211-220) and,
+// One thread per cluster, 4 rounds of 512 per block: size threshold (src/utils.cpp:211-220) and,
 // for the clusters kept, the summary row {first hit, size, read, prg << 1 | !forward, first
 // position, last position, path rank of the first hit, cluster number} at the chained prefix sum of
 // the kept counts.  The last block writes the kept total.
-static const uint32_t KEEP_THREADS = 512, KEEP_WAVES = KEEP_THREADS / 64, KEEP_ROUNDS = 2, KEEP_BLOCK = KEEP_THREADS * KEEP_ROUNDS;
+static const uint32_t KEEP_THREADS = 512, KEEP_WAVES = KEEP_THREADS / 64, KEEP_ROUNDS = 4, KEEP_BLOCK = KEEP_THREADS * KEEP_ROUNDS;
 
 template <bool SERIAL>
 __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__restrict__ dc, uint32_t cl_cap,
