@@ -120,6 +120,7 @@ typedef struct {
     uint32_t n_prg;
     uint32_t filter_bits;           /* log2 of the size of the presence filter in bits, 0 = none */
     uint32_t filter_bits_per_key;   /* 1 or 2 (0 without a filter) */
+    uint32_t filter_direct;         /* 1: the filter is a bitmap over the whole key range (bit = key), exact */
 } pmap_index_info_t;
 int pmap_index_info(const pmap_index_t *idx, pmap_index_info_t *info);
 

@@ -28,7 +28,8 @@ class IndexDesc(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_uint32), ("n_keys", C.c_uint64), ("n_recs", C.c_uint64), ("n_paths", C.c_uint64),
                 ("table_slots", C.c_uint64), ("device_bytes", C.c_uint64), ("n_prg", C.c_uint32),
-                ("filter_bits", C.c_uint32), ("filter_bits_per_key", C.c_uint32)]
+                ("filter_bits", C.c_uint32), ("filter_bits_per_key", C.c_uint32),
+                ("filter_direct", C.c_uint32)]
 
 
 class Params(C.Structure):

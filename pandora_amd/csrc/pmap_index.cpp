@@ -238,13 +238,28 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
     uint32_t fbits = std::min<uint32_t>(log2cap + 3, max_fbits);
     if (idx->n_keys * 4 > (1ull << fbits)) fbits = 0;
     else if (idx->n_keys * 16 > (1ull << fbits)) fbits |= PMAP_FILTER_TWO;
+    // Too many keys for a filter of that size: a bitmap over the whole key range when that has at most 2^30
+    // values (k <= 15) and the keys crowd its low end, as the minimizers of windows of several k-mers do
+    // (lookups then fall where the keys are, and the busy part of the bitmap stays cached; measured on a
+    // 25 M-key index with w = 14: lookup phase 0.71 -> 0.50 ms).  Keys spread evenly over the range (w = 1:
+    // every k-mer) gain nothing from it: half of the lookups find their key, and the bitmap is one more
+    // request for each.  PMAP_FILTER_DIRECT=0 / 1: never / for every index with k <= 15 (tests).
+    int direct = 0;
+    if (fbits == 0 && idx->k <= 15 && !ukeys.empty()) {
+        const uint64_t low_end = (1ull << (2 * idx->k)) >> 3;
+        uint64_t low = 0;
+        for (uint64_t key : ukeys) low += key < low_end;
+        direct = 2 * low >= ukeys.size();
+    }
+    if (const char *dir_env = getenv("PMAP_FILTER_DIRECT")) direct = atoi(dir_env) != 0;
+    if (direct && idx->k >= 3 && idx->k <= 15) fbits = 2 * idx->k | PMAP_FILTER_DIRECT;
     idx->filter_bits = fbits;
     idx->filter.clear();
     if (fbits) {
         idx->filter.assign((size_t) 1 << ((fbits & 0xFFu) - 5), 0u);
         for (size_t i = 0; i < ukeys.size(); ++i) {
             const uint32_t hm = pmap_key_mix(ukeys[i]);
-            idx->filter[pmap_filter_word(hm, fbits)] |= pmap_filter_mask(hm, fbits);
+            idx->filter[pmap_filter_word(ukeys[i], hm, fbits)] |= pmap_filter_mask(ukeys[i], hm, fbits);
         }
     }
     clk.lap("table + filter");
@@ -545,8 +560,9 @@ extern "C" int pmap_index_load_cache(const char *cache_path, pmap_index_t **out)
     if (h.version != CACHE_VERSION) return bad("written by another version");
     const uint32_t fb = h.filter_bits & 0xFFu;     // number of filter bits; PMAP_FILTER_TWO rides above it
     if (h.k < 1 || h.k > 31 || h.log2cap > 31 || h.n_slots != (1ull << h.log2cap) || h.n_recs >= 0xFFFFFFFFull ||
-        h.n_keys > h.n_recs || (h.filter_bits & ~(0xFFu | PMAP_FILTER_TWO)) || fb > 30 || (fb && fb < 6) ||
-        (!fb && h.filter_bits) || h.n_filter_words != (fb ? (1ull << (fb - 5)) : 0))
+        h.n_keys > h.n_recs || (h.filter_bits & ~(0xFFu | PMAP_FILTER_TWO | PMAP_FILTER_DIRECT)) || fb > 30 || (fb && fb < 6) ||
+        (!fb && h.filter_bits) || ((h.filter_bits & PMAP_FILTER_DIRECT) && (fb != 2 * h.k || (h.filter_bits & PMAP_FILTER_TWO))) ||
+        h.n_filter_words != (fb ? (1ull << (fb - 5)) : 0))
         return bad("inconsistent header");
     // the file must be exactly as long as the header says, before anything is allocated from it
     uint64_t expect = sizeof(h) + 8;
@@ -666,6 +682,7 @@ extern "C" int pmap_index_info(const pmap_index_t *idx, pmap_index_info_t *info)
     info->n_prg = idx->n_prg;
     info->filter_bits = idx->filter_bits & 0xFFu;
     info->filter_bits_per_key = !idx->filter_bits ? 0u : (idx->filter_bits & PMAP_FILTER_TWO) ? 2u : 1u;
+    info->filter_direct = (idx->filter_bits & PMAP_FILTER_DIRECT) ? 1u : 0u;
     return PMAP_OK;
 }
 

@@ -44,13 +44,23 @@ PMAP_HD static inline uint32_t pmap_key_mix(uint64_t key) {
 PMAP_HD static inline uint32_t pmap_slot_of(uint64_t key, uint32_t log2cap) {
     return pmap_key_mix(key) >> (32 - log2cap);
 }
-// Presence filter over hm = pmap_key_mix(key).  `fb` = number of bits of the filter (its low byte,
-// 0 = no filter), with PMAP_FILTER_TWO when every key sets two bits of its 32-bit word instead of
-// one (denser indexes: the false-positive rate is about the square of the fill instead of the fill).
+// Presence filter.  `fb` = log2 of the number of bits of the filter in its low byte (0 = no filter) plus
+// flags.  Hashed form: bit pmap_key_mix(key) >> (32 - bits); with PMAP_FILTER_TWO every key sets two
+// bits of its 32-bit word instead of one (denser indexes: the false-positive rate is about the square of
+// the fill instead of the fill).  PMAP_FILTER_DIRECT: bit number = the key itself, for keys below 2^bits
+// (k <= 15: 2^30 bits = 128 MiB) - exact, so the table is read only for keys it holds, and since
+// minimizers are window minima their keys crowd the low end of the range, which keeps the busy part of
+// the bitmap in the caches however many keys the index has.
 static const uint32_t PMAP_FILTER_TWO = 0x100u;
-PMAP_HD static inline uint32_t pmap_filter_word(uint32_t hm, uint32_t fb) { return hm >> (32 - (fb & 0xFFu)) >> 5; }
-PMAP_HD static inline uint32_t pmap_filter_mask(uint32_t hm, uint32_t fb) {
-    uint32_t m = 1u << ((hm >> (32 - (fb & 0xFFu))) & 31u);
+static const uint32_t PMAP_FILTER_DIRECT = 0x200u;
+PMAP_HD static inline uint32_t pmap_filter_bit(uint64_t key, uint32_t hm, uint32_t fb) {
+    return (fb & PMAP_FILTER_DIRECT) ? (uint32_t) key : hm >> (32 - (fb & 0xFFu));
+}
+PMAP_HD static inline uint32_t pmap_filter_word(uint64_t key, uint32_t hm, uint32_t fb) {
+    return pmap_filter_bit(key, hm, fb) >> 5;
+}
+PMAP_HD static inline uint32_t pmap_filter_mask(uint64_t key, uint32_t hm, uint32_t fb) {
+    uint32_t m = 1u << (pmap_filter_bit(key, hm, fb) & 31u);
     if (fb & PMAP_FILTER_TWO) m |= 1u << ((hm >> 3) & 31u);      // hash bits the word index does not use
     return m;
 }

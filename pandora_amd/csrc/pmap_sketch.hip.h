@@ -281,8 +281,8 @@ __device__ __forceinline__ void index_lookup(const PmapSlot *__restrict__ slots,
     *first = make_uint4(0, 0, 0, 0);
     const uint32_t hm = pmap_key_mix(key);
     if (fbits) {
-        const uint32_t m = pmap_filter_mask(hm, fbits);
-        if ((filt[pmap_filter_word(hm, fbits)] & m) != m) return;
+        const uint32_t m = pmap_filter_mask(key, hm, fbits);
+        if ((filt[pmap_filter_word(key, hm, fbits)] & m) != m) return;
     }
     const uint32_t capmask = (1u << log2cap) - 1;
     uint32_t s = hm >> (32 - log2cap);
@@ -797,7 +797,7 @@ __device__ __forceinline__ bool sketch_dpp_tile(
                         fw[r] = 0xFFFFFFFFu;
                         if (fbits) {
                             const uint32_t hm = pmap_key_mix((uint64_t) le[r].x);
-                            fb[r] = hm >> fsh;                                  // pmap_filter_word / pmap_filter_mask
+                            fb[r] = (fbits & PMAP_FILTER_DIRECT) ? le[r].x : hm >> fsh;     // pmap_filter_bit
                             if (fbits & PMAP_FILTER_TWO) fb2[r] = hm >> 3;
                             fw[r] = filt[fb[r] >> 5];
                         }

@@ -1,6 +1,6 @@
 """GPU parity on the index shapes and inputs the benchmark configurations name: PRGs with variant sites
 (multi-interval paths) and gene families (several records per key), a 200 000-locus index whose table is
-beyond every cache and has no presence filter, the real reads the reference ships, and an index that
+beyond every cache (with the key-range bitmap in front of it and with no filter at all), the real reads the reference ships, and an index that
 arrives as the reference's `.idx` text and as its binary cache."""
 import os
 
@@ -51,14 +51,20 @@ def test_workload_families_slice(gpu):
     assert cn["n_hits"] > 20000
 
 
-def test_200k_locus_index_slices(gpu):
-    """200 000 loci: 27 M keys, a 2 GB slot table in HBM with no presence filter in front of it (every
-    minimizer probes the table).  A slice of the nanopore reads and 3 000 reads of 150 bases with w = 1
-    (every k-mer probes) against the oracle over the same index."""
+@pytest.mark.parametrize("direct", [None, "0"])
+def test_200k_locus_index_slices(gpu, monkeypatch, direct):
+    """200 000 loci: 27 M keys, a 2 GB slot table in HBM.  No hashed presence filter is worth having at that
+    many keys: the library puts a bitmap over the whole key range in front of the table (minimizer keys crowd
+    the low end of the range), or, with PMAP_FILTER_DIRECT=0, nothing (every minimizer probes the table).
+    A slice of the nanopore reads and 3 000 reads of 150 bases with w = 1 (every k-mer probes) against the
+    oracle over the same index."""
+    if direct is not None:
+        monkeypatch.setenv("PMAP_FILTER_DIRECT", direct)
     si, bases, off, prm = synth.workload("nanopore_200k", seed=1, scale=0.01)
     gidx = gpu_index(si)
     info = gidx.info()
-    assert info["n_keys"] > 25_000_000 and info["filter_bits_per_key"] == 0 and info["table_slots"] * 32 >= (2 << 30)
+    assert info["n_keys"] > 25_000_000 and info["table_slots"] * 32 >= (2 << 30)
+    assert (info["filter_direct"], info["filter_bits_per_key"]) == ((1, 1) if direct is None else (0, 0))
     n = min(150, len(off) - 1)
     sub_off = off[:n + 1]
     frac = api.fraction(prm["e_rate"], prm["k"])

@@ -305,20 +305,33 @@ def test_sort_segment_sizes(gpu):
 
 
 def test_presence_filter_modes(gpu, monkeypatch):
-    """The presence filter in front of the table has one bit per key, two bits per key (dense indexes)
-    or is absent (very dense ones).  PMAP_FILTER_MAX_BITS shrinks it so that a small index reaches every
-    mode; results must not depend on it."""
+    """The presence filter in front of the table has one bit per key, two bits per key (dense indexes),
+    is absent, or is a bitmap over the whole key range (k <= 15; what big indexes of sparse sketches get).
+    PMAP_FILTER_MAX_BITS shrinks it so that a small index reaches every hashed mode and PMAP_FILTER_DIRECT
+    chooses the bitmap; results must not depend on it."""
     si, bases, off = _small_world(31, 14, 15, n_loci=12, n_reads=40)
     seen = set()
-    for max_bits in ("24", "16", "14", "12"):
+    for max_bits, direct in (("24", "0"), ("16", "0"), ("14", "0"), ("12", "0"), ("12", "1"), ("12", None)):
         monkeypatch.setenv("PMAP_FILTER_MAX_BITS", max_bits)
+        if direct is None:
+            monkeypatch.delenv("PMAP_FILTER_DIRECT")     # the library's own choice: minimizer keys crowd the low end
+        else:
+            monkeypatch.setenv("PMAP_FILTER_DIRECT", direct)
         gidx = gpu_index(si)
         info = gidx.info()
-        seen.add(info["filter_bits_per_key"])
+        assert info["filter_direct"] == (direct != "0") and (not info["filter_direct"] or info["filter_bits"] == 30)
+        seen.add((info["filter_bits_per_key"], info["filter_direct"]))
         compare_batch(si, bases, off, 14, 15, 250, api.fraction(0.11, 15), gidx=gidx)
         compare_batch(si, bases, off, 9, 15, 250, api.fraction(0.11, 15), gidx=gidx)     # general sketch kernel
         gidx.close()
-    assert seen == {0, 1, 2}, seen
+    assert seen == {(0, 0), (1, 0), (2, 0), (1, 1)}, seen
+    # keys below 2^(2k) for a smaller k: the bitmap has 2^(2k) bits
+    si, bases, off = _small_world(32, 5, 7, n_loci=6, n_reads=30)
+    monkeypatch.setenv("PMAP_FILTER_DIRECT", "1")
+    gidx = gpu_index(si)
+    assert gidx.info()["filter_direct"] == 1 and gidx.info()["filter_bits"] == 14
+    compare_batch(si, bases, off, 5, 7, 30, api.fraction(0.11, 7), min_cluster_size=2, gidx=gidx)
+    gidx.close()
 
 
 def test_megabase_reads(gpu):
