@@ -183,6 +183,12 @@ typedef struct {
 /* Diagnostic: sort with the kernel variant for indexes of more than 2^19 loci (keys too wide to share a
  * word with a position) whatever the index. */
 #define PMAP_FLAG_SORT_WIDE 8u
+/* Diagnostic: reads of middling hit counts (320 < hits <= 2048 by default; PMAP_SORT_WAVE_MIN / _MAX, read
+ * by pmap_init) are sorted by one wavefront each with a network in registers; with PMAP_FLAG_SORT_NO_WAVE they
+ * take the rank-counting sort like shorter reads, with PMAP_FLAG_TEST_SORT_WAVE_ALL every read of 2 to 2048
+ * hits takes the wavefront sort.  Results are the same. */
+#define PMAP_FLAG_SORT_NO_WAVE 32u
+#define PMAP_FLAG_TEST_SORT_WAVE_ALL 64u
 /* Test hook: the prefix sums that chain the workgroups of the cluster kernels give up at their first wait, as
  * they would after a very long one, so that the batch takes the fallback (one workgroup per kernel) it takes
  * then.  Results are the same. */

@@ -73,6 +73,9 @@ enum SketchKind { SKETCH_LDS = 0, SKETCH_DPP8 = 8, SKETCH_DPP16 = 16 };
 static SketchKind g_sketch_pref = SKETCH_DPP16;
 // reads with more hits than this are sorted by the long-segment kernels (PMAP_SORT_LONG overrides, for experiments)
 static uint32_t g_sort_long = 4096;
+// reads with more than g_sort_wave_min and at most g_sort_wave_max hits: sort_wave_kernel (one wavefront per read)
+static const uint32_t SORT_WAVE_LIMIT = 2048;      // = 64 * SORT_WAVE_E of the kernel
+static uint32_t g_sort_wave_min = 320, g_sort_wave_max = SORT_WAVE_LIMIT;
 
 // ---------------------------------------------------------------------------
 // Scratch memory of pmap_map_noalloc, the entry point that allocates nothing: everything pmap_map keeps
@@ -91,8 +94,8 @@ static const size_t NA_MAX_TILES = NA_MAX_SLOTS / 512;   // the smallest slot st
 static const size_t NA_OFF_STATE = 0;                                                      // 256 KiB
 static const size_t NA_OFF_GROUP = NA_OFF_STATE + (256u << 10);                            // 64 KiB
 static const size_t NA_OFF_TILECNT = NA_OFF_GROUP + (64u << 10);                           // 16 B per tile
-static const size_t NA_OFF_HBOUNDS = NA_OFF_TILECNT + 16 * (NA_MAX_TILES + 16);            // 8 B per read
-static const size_t NA_OFF_THR = NA_OFF_HBOUNDS + 8 * (NA_MAX_READS + 32);                 // 4 B per prg
+static const size_t NA_OFF_HBOUNDS = NA_OFF_TILECNT + 16 * (NA_MAX_TILES + 16);            // 12 (of 16) B per read
+static const size_t NA_OFF_THR = NA_OFF_HBOUNDS + 16 * (NA_MAX_READS + 32);                // 4 B per prg
 static const size_t NA_OFF_CSTART = NA_OFF_THR + 4 * (NA_MAX_PRG + 64);                    // 4 B per cluster
 static const size_t NA_OFF_HITS = NA_OFF_CSTART + 4 * (NA_MAX_CLUSTERS + 64);              // 5 x 4 B per hit
 static const size_t NA_OFF_ENTS = NA_OFF_HITS + 5 * 4 * NA_MAX_HITS;                       // 32 B per tile slot
@@ -145,6 +148,8 @@ extern "C" int pmap_init(int device) {
     const char *sk = getenv("PMAP_SKETCH");
     g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
     if (const char *sl = getenv("PMAP_SORT_LONG")) g_sort_long = (uint32_t) std::max(1, atoi(sl));
+    if (const char *sw = getenv("PMAP_SORT_WAVE_MIN")) g_sort_wave_min = (uint32_t) std::max(0, atoi(sw));
+    if (const char *sw = getenv("PMAP_SORT_WAVE_MAX")) g_sort_wave_max = (uint32_t) std::min((int) SORT_WAVE_LIMIT, std::max(0, atoi(sw)));
     if (device < 0) {
         if (t_ctx) return PMAP_OK;
         HIP_TRY(hipGetDevice(&device));
@@ -287,7 +292,9 @@ struct Counters {
     uint32_t has_long;            // some read has more hits than the rank-counting sort takes: the long-segment kernels have work
     uint32_t dense_marks;         // sum of tile_cnt.w: tiles with more minimizers than the sketch kernel's list holds (1 each: left
                                   // out, the overflow kernel has work; 2 each: done by it)
-    uint32_t pad[3];
+    uint32_t n_wave;              // reads on the list of the wavefront sort
+    uint32_t has_wave;            // some read has a hit count the wavefront sort is for
+    uint32_t pad[1];
 };
 static_assert(sizeof(Counters) == 64, "Counters is the head of the state block");
 
@@ -360,7 +367,8 @@ struct pmap_result {
     DevBuf mkmer, ents;
     // hits before / after sort
     DevBuf h_read, h_key, h_pos, h_rank, h_rec;
-    DevBuf hbounds;   // per read: first hit, then ~(one past the last hit); all-ones before every run
+    DevBuf hbounds;   // per read: first hit, then ~(one past the last hit); all-ones before every run; behind them the list
+                      // of reads for the wavefront sort
     DevBuf s_read, s_key, s_pos, s_rank, s_rec;
     DevBuf long_words;   // sort of reads with very many hits: the hit array's blocks, each sorted (8 bytes per hit)
     // clusters
@@ -384,6 +392,7 @@ struct pmap_result {
     uint32_t p_last = 0;
     bool long_enabled = false;        // launch the long-segment sort kernels
     bool long_launched = false;       // ... and the last run did
+    bool wave_enabled = true;         // launch the wavefront sort kernels (off after a batch without a read for them)
     bool dense_enabled = false;       // launch the sketch kernel for tiles with more minimizers than the usual one's list holds
     bool dense_launched = false;
     bool serial_scans = false;        // this run replaces the chained prefix sums by one workgroup per kernel
@@ -809,17 +818,46 @@ static int run_pipeline(pmap_result *res) {
         kt.begin(KT_SORT);
         // (a read has at most one minimizer per base and a minimizer at most max_cnt hits)
         res->long_launched = res->long_enabled && (uint64_t) rd->max_len * idx->max_cnt > g_sort_long;
+        // Reads of middling hit counts go to sort_wave_kernel, whose words hold a key and a place of up to
+        // 6 + log2 SORT_WAVE_E bits (PMAP_FLAG_SORT_NO_WAVE: none do; PMAP_FLAG_TEST_SORT_WAVE_ALL: every read
+        // of 2 hits or more up to the kernel's limit does)
+        uint32_t wave_min = g_sort_wave_min, wave_max = g_sort_wave_max;
+        uint32_t *wave_list = res->hbounds.as<uint32_t>() + 2 * ((size_t) rd->n_reads + 1);     // behind the bounds
+        if (prm->flags & PMAP_FLAG_TEST_SORT_WAVE_ALL) wave_min = 1, wave_max = SORT_WAVE_LIMIT;
+        // (a read has at most one minimizer per base and a minimizer at most max_cnt hits)
+        const uint64_t most_hits = (uint64_t) rd->max_len * idx->max_cnt;
+        if ((prm->flags & PMAP_FLAG_SORT_NO_WAVE) || 2ull * idx->n_prg * SORT_WAVE_LIMIT > (1ull << 32) || wave_min >= wave_max ||
+            most_hits <= wave_min)
+            wave_min = wave_max = 0;
+        const bool wave_launched = wave_max && (res->wave_enabled || (prm->flags & PMAP_FLAG_TEST_SORT_WAVE_ALL));
 #define SORT_ARGS                                                                                                     \
     &dc->n_hits, res->hit_cap, res->h_read.as<uint32_t>(), res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(),      \
         res->h_rank.as<uint32_t>(), res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,          \
         res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), \
-        res->s_rec.as<uint32_t>(), &dc->has_long, g_sort_long, res->long_launched ? 1u : 0u
+        res->s_rec.as<uint32_t>(), &dc->has_long, g_sort_long, res->long_launched ? 1u : 0u, wave_min, wave_max,      \
+        wave_launched ? 1u : 0u, &dc->has_wave
         // keys are prg << 1 | strand: narrow enough to share a word with a place in the staged chunk?
         if (2ull * idx->n_prg <= (1ull << (31 - SORT_CH_BITS)) && !(prm->flags & PMAP_FLAG_SORT_WIDE))
             KLAUNCH(sort_rank_kernel<true>, dim3(res->hit_cap / 256), SORT_ARGS);
         else
             KLAUNCH(sort_rank_kernel<false>, dim3(res->hit_cap / 256), SORT_ARGS);
 #undef SORT_ARGS
+        static_assert(SORT_WAVE_LIMIT == 64 * SORT_WAVE_E, "the kernel's largest network");
+#define SORT_WAVE_ARGS                                                                                                \
+    &dc->n_hits, res->hit_cap, res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(),      \
+        res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1, res->s_read.as<uint32_t>(),          \
+        res->s_key.as<uint32_t>(), res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->s_rec.as<uint32_t>(),  \
+        g_sort_long, wave_min, wave_max, &dc->n_wave, wave_list
+        if (wave_launched) {
+            // at most a read per wave_min hits is on the list; a wavefront takes several in turn beyond 32768 reads
+            const uint32_t wave_grid = (uint32_t) std::min<uint64_t>(8192, std::min<uint64_t>(rd->n_reads, res->hit_cap / std::max(wave_min, 1u)) / 4 + 1);
+            KLAUNCH(sort_wave_list_kernel, dim3((rd->n_reads + 1 + 255) / 256), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
+                    g_sort_long, wave_min, wave_max, &dc->n_wave, wave_list);
+            KLAUNCH(sort_wave_kernel<false>, dim3(wave_grid), SORT_WAVE_ARGS);
+            if (wave_max > SORT_WAVE_LIMIT / 2 && most_hits > SORT_WAVE_LIMIT / 2)
+                KLAUNCH(sort_wave_kernel<true>, dim3(wave_grid), SORT_WAVE_ARGS);
+        }
+#undef SORT_WAVE_ARGS
         // Reads with more hits than the rank counting takes.  Such reads are rare: the two kernels are launched
         // only once a batch has turned out to hold one (pmap_map_wait then maps the batch again with them, and
         // they stay on until a batch comes without such a read).
@@ -932,7 +970,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     const uint32_t n_tiles = res->n_tiles;
     const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * res->tile_stride;
     if ((rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) || (rc = res->ents.ensure(8 * sb)) ||
-        (rc = res->hbounds.ensure(sizeof(uint32_t) * 2 * ((size_t) rd->n_reads + 1))))
+        (rc = res->hbounds.ensure(sizeof(uint32_t) * 3 * ((size_t) rd->n_reads + 1))))
         return rc;
     if (!fused && (rc = res->mkmer.ensure(2 * sb))) return rc;
 
@@ -1002,6 +1040,7 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
             continue;
         }
         res->long_enabled = hc.has_long != 0;
+        res->wave_enabled = hc.has_wave != 0;
         if (hc.dense_marks && !res->dense_launched) {
             // a tile with more minimizers than the sketch kernel's list holds (low-complexity sequence) was left
             // out: once more with the kernel that takes such tiles behind it; it stays on until a batch comes
@@ -1220,6 +1259,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     }
     res->dense_enabled = res->hc->dense_marks != 0;
     res->long_enabled = res->hc->has_long != 0;
+    res->wave_enabled = res->hc->has_wave != 0;
     const Counters &hc = *res->hc;
     counts->n_reads = rd->n_reads;
     counts->n_bases = rd->n_bases;

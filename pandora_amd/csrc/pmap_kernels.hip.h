@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
                                                         uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
                                                         uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
                                                         uint32_t *__restrict__ s_rec, uint32_t *__restrict__ has_long, uint32_t sort_long,
-                                                        uint32_t long_follows) {
+                                                        uint32_t long_follows, uint32_t wave_min, uint32_t wave_max,
+                                                        uint32_t wave_follows, uint32_t *__restrict__ has_wave) {
     __shared__ uint32_t keys[SORT_CH];
     __shared__ uint32_t wlo[4], whi[4];
     const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
@@ -317,6 +318,11 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
                 s_rank[i] = h_rank[i];
                 s_rec[i] = h_rec[i];
             }
+        } else if (e - s > wave_min && e - s <= wave_max) {
+            // sort_wave_kernel's kind of read: left to it when it is part of this run, and the host hears of it
+            // either way (it runs that kernel only while batches hold such reads)
+            if (wave_follows) active = false;
+            *has_wave = 1u;             // every writer stores the same value
         }
     }
     // the stretch of hits this block's reads cover: from the first active thread's read to the last one's
@@ -364,6 +370,269 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const unsigned long long
         s_rank[d] = h_rank[i];
         s_rec[d] = h_rec[i];
     }
+}
+
+// ---------------------------------------------------------------------------
+// Reads with more hits than a comparison per pair of hits is good for (wave_min) and at most 64 * SORT_WAVE_E
+// (wave_max): one wavefront per read sorts the words {key, place in the read's segment} with a bitonic network
+// held in registers, E words per lane (word i of the segment in lane i / E, register i % E), then moves every
+// hit to the place its word ended at.  About 100 instructions per word for 512 hits, whatever the keys are,
+// against 2 per pair of hits for the rank counting (the 470 hits of a read on a 200 000-locus index: 930).
+// The network is the all-ascending form: a merge of blocks of 2m words starts with the step that compares word
+// i with word i ^ (2m - 1) (its mirror image in the block) and goes on with steps i ^ m/2, i ^ m/4, ..., 1.
+// Steps inside a lane are min / max of two registers; steps across lanes take the other word through a DPP
+// permutation (lanes ^ 1, 2, 3, 7, 8, 15), a ds_swizzle (^ 4, 16, 31) or a ds_bpermute (^ 32, 63).
+static const int SORT_WAVE_E = 32;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t x) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, 0xf, 0xf, true);      // every lane has a source lane
+}
+
+// x of lane (lane ^ XM)
+template <int XM>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, uint32_t lane) {
+    if constexpr (XM == 1) return dpp_perm<0xB1>(x);                // quad_perm [1,0,3,2]
+    else if constexpr (XM == 2) return dpp_perm<0x4E>(x);           // quad_perm [2,3,0,1]
+    else if constexpr (XM == 3) return dpp_perm<0x1B>(x);           // quad_perm [3,2,1,0]
+    else if constexpr (XM == 7) return dpp_perm<0x141>(x);          // row_half_mirror
+    else if constexpr (XM == 8) return dpp_perm<0x128>(x);          // row_ror:8
+    else if constexpr (XM == 15) return dpp_perm<0x140>(x);         // row_mirror
+    else if constexpr (XM == 4) return (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x101F);    // and 0x1f, xor 4
+    else if constexpr (XM == 16) return (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x401F);   // xor 16
+    else if constexpr (XM == 31) return (uint32_t) __builtin_amdgcn_ds_swizzle((int) x, 0x7C1F);   // xor 31
+    else {
+        static_assert(XM == 32 || XM == 63, "no permutation for this lane distance");
+        return (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((lane ^ (uint32_t) XM) << 2), (int) x);
+    }
+}
+
+// compare-exchange with lane ^ XM: lanes with BIT clear keep the smaller word.  MIRROR: the other word is
+// register E-1-j of that lane instead of register j.
+template <int E, int XM, int BIT, bool MIRROR>
+__device__ __forceinline__ void sortw_lane_step(uint32_t (&v)[E], uint32_t lane) {
+    const bool lower = (lane & (uint32_t) BIT) == 0;
+    uint32_t o[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t p = lane_xor<XM>(v[MIRROR ? E - 1 - j : j], lane);
+        const uint32_t lo = min(v[j], p), hi = max(v[j], p);
+        o[j] = lower ? lo : hi;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] = o[j];
+}
+
+// compare-exchange of registers j and j ^ X (X = STRIDE, or SIZE - 1 for the mirror step) inside every lane
+template <int E, int X, int LOWBIT>
+__device__ __forceinline__ void sortw_reg_step(uint32_t (&v)[E]) {
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+        if ((j & LOWBIT) == 0) {
+            const int jj = j ^ X;
+            const uint32_t a = v[j], b = v[jj];
+            v[j] = min(a, b);
+            v[jj] = max(a, b);
+        }
+}
+
+// the steps i ^ STRIDE, i ^ STRIDE/2, ..., i ^ 1 inside the lanes
+template <int E, int STRIDE>
+__device__ __forceinline__ void sortw_reg_tail(uint32_t (&v)[E]) {
+    if constexpr (STRIDE >= 1) {
+        sortw_reg_step<E, STRIDE, STRIDE>(v);
+        sortw_reg_tail<E, STRIDE / 2>(v);
+    }
+}
+
+// merges of blocks of SIZE = 2, 4, ..., E registers inside every lane
+template <int E, int SIZE>
+__device__ __forceinline__ void sortw_reg_merges(uint32_t (&v)[E]) {
+    if constexpr (SIZE <= E) {
+        sortw_reg_step<E, SIZE - 1, SIZE / 2>(v);
+        sortw_reg_tail<E, SIZE / 4>(v);
+        sortw_reg_merges<E, 2 * SIZE>(v);
+    }
+}
+
+// the steps lane ^ S, lane ^ S/2, ..., lane ^ 1
+template <int E, int S>
+__device__ __forceinline__ void sortw_lane_tail(uint32_t (&v)[E], uint32_t lane) {
+    if constexpr (S >= 1) {
+        sortw_lane_step<E, S, S, false>(v, lane);
+        sortw_lane_tail<E, S / 2>(v, lane);
+    }
+}
+
+// merges of blocks of LB = 2, 4, ..., 64 lanes
+template <int E, int LB>
+__device__ __forceinline__ void sortw_lane_merges(uint32_t (&v)[E], uint32_t lane) {
+    if constexpr (LB <= 64) {
+        sortw_lane_step<E, LB - 1, LB / 2, true>(v, lane);
+        sortw_lane_tail<E, LB / 4>(v, lane);
+        sortw_reg_tail<E, E / 2>(v);
+        sortw_lane_merges<E, 2 * LB>(v, lane);
+    }
+}
+
+// The reads sort_wave_kernel takes (wave_min < hits <= wave_max, and not beyond sort_long), as a list: one thread
+// per read, one atomic per wavefront.  (One atomic per read from sort_rank_kernel, whose threads see the same
+// bounds, doubled that kernel's time: 15 000 of them on one word wait for each other.)
+__global__ __launch_bounds__(256) void sort_wave_list_kernel(const uint32_t *__restrict__ hbounds, uint32_t n_reads,
+                                                             uint32_t sort_long, uint32_t wave_min, uint32_t wave_max,
+                                                             uint32_t *__restrict__ wave_n, uint32_t *__restrict__ wave_list) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    bool take = false;
+    if (r < n_reads) {
+        const uint32_t s = hbounds[r], e = ~hbounds[n_reads + r];       // a read without hits has s = all-ones, e = 0
+        take = s < e && e - s > wave_min && e - s <= wave_max && e - s <= sort_long;
+    }
+    const unsigned long long m = ballot64(take);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(wave_n, (uint32_t) __popcll(m));
+    base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+    if (take) wave_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0))] = r;
+}
+
+// four consecutive 32-bit words at any 4-byte boundary
+struct __attribute__((aligned(4))) Quad4 {
+    uint32_t x, y, z, w;
+};
+
+template <int E>
+__device__ __forceinline__ void sort_wave_segment(uint32_t lane, uint32_t r, uint32_t s, uint32_t n,
+                                                  const uint32_t *__restrict__ h_key, const uint32_t *__restrict__ h_pos,
+                                                  const uint32_t *__restrict__ h_rank, const uint32_t *__restrict__ h_rec,
+                                                  uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
+                                                  uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
+                                                  uint32_t *__restrict__ s_rec) {
+    constexpr uint32_t PB = 6 + (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : E == 16 ? 4 : 5), PM = (1u << PB) - 1;
+    static_assert(E == 1 || E == 2 || E == 4 || E == 8 || E == 16 || E == 32, "a power of two");
+    uint32_t v[E];
+    // a lane's E words are consecutive in memory: 16-byte accesses where the whole group of 4 is inside the segment
+    // (the segment starts at any multiple of 4 bytes)
+    const uint32_t i0 = lane * E;
+    if constexpr (E >= 4) {
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const uint32_t i = i0 + 4 * q;
+            uint32_t kk[4] = {0, 0, 0, 0};
+            if (i + 4 <= n) {
+                const Quad4 t = *(const Quad4 *) (h_key + s + i);
+                kk[0] = t.x; kk[1] = t.y; kk[2] = t.z; kk[3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < n) kk[u] = h_key[s + i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * q + u] = i + u < n ? (kk[u] << PB | (i + u)) : 0xFFFFFFFFu;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t i = i0 + j;
+            v[j] = i < n ? (h_key[s + i] << PB | i) : 0xFFFFFFFFu;      // words past the end sort behind every hit
+        }
+    }
+    sortw_reg_merges<E, 2>(v);
+    sortw_lane_merges<E, 2>(v, lane);
+    if constexpr (E >= 4) {
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const uint32_t i = i0 + 4 * q, d = s + i;
+            if (i >= n) continue;
+            uint32_t from[4], ps[4], rk[4], rc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                from[u] = s + (v[4 * q + u] & PM);
+                const bool in = i + u < n;
+                ps[u] = in ? h_pos[from[u]] : 0u;
+                rk[u] = in ? h_rank[from[u]] : 0u;
+                rc[u] = in ? h_rec[from[u]] : 0u;
+            }
+            if (i + 4 <= n) {
+                *(Quad4 *) (s_read + d) = Quad4{r, r, r, r};
+                *(Quad4 *) (s_key + d) = Quad4{v[4 * q] >> PB, v[4 * q + 1] >> PB, v[4 * q + 2] >> PB, v[4 * q + 3] >> PB};
+                *(Quad4 *) (s_pos + d) = Quad4{ps[0], ps[1], ps[2], ps[3]};
+                *(Quad4 *) (s_rank + d) = Quad4{rk[0], rk[1], rk[2], rk[3]};
+                *(Quad4 *) (s_rec + d) = Quad4{rc[0], rc[1], rc[2], rc[3]};
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < n) {
+                        s_read[d + u] = r;
+                        s_key[d + u] = v[4 * q + u] >> PB;
+                        s_pos[d + u] = ps[u];
+                        s_rank[d + u] = rk[u];
+                        s_rec[d + u] = rc[u];
+                    }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t i = i0 + j;
+            if (i < n) {
+                const uint32_t from = s + (v[j] & PM), d = s + i;
+                s_read[d] = r;
+                s_key[d] = v[j] >> PB;
+                s_pos[d] = h_pos[from];
+                s_rank[d] = h_rank[from];
+                s_rec[d] = h_rec[from];
+            }
+        }
+    }
+}
+
+// The reads of wave_list[0 .. *wave_n) (sort_wave_list_kernel), one wavefront per read at a time, any grid.
+// BIG = false: reads of up to 1024 hits; BIG = true: of 1025 to 2048 hits (its 32 words per lane take 92 registers
+// instead of 56: a kernel of its own, so that the shorter reads keep 8 wavefronts per SIMD to hide their loads).
+// Keys must be below 2^(32 - 6 - log2 SORT_WAVE_E) (the host checks the index).
+template <bool BIG>
+__global__ __launch_bounds__(256) void sort_wave_kernel(const unsigned long long *__restrict__ n_hits_p, uint32_t hit_cap,
+                                                        const uint32_t *__restrict__ h_key,
+                                                        const uint32_t *__restrict__ h_pos,
+                                                        const uint32_t *__restrict__ h_rank,
+                                                        const uint32_t *__restrict__ h_rec,
+                                                        const uint32_t *__restrict__ hbounds, uint32_t n_reads,
+                                                        uint32_t *__restrict__ s_read, uint32_t *__restrict__ s_key,
+                                                        uint32_t *__restrict__ s_pos, uint32_t *__restrict__ s_rank,
+                                                        uint32_t *__restrict__ s_rec, uint32_t sort_long,
+                                                        uint32_t wave_min, uint32_t wave_max,
+                                                        const uint32_t *__restrict__ wave_n,
+                                                        const uint32_t *__restrict__ wave_list) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint32_t n_hits = clamp_count(n_hits_p, hit_cap);
+    const uint32_t n_list = min(*wave_n, n_reads);
+    for (uint32_t t = wave; t < n_list; t += gridDim.x * 4) {       // wave-uniform
+        const uint32_t r = (uint32_t) __builtin_amdgcn_readfirstlane((int) wave_list[t]);
+        if (r >= n_reads) continue;
+        const uint32_t s = (uint32_t) __builtin_amdgcn_readfirstlane((int) hbounds[r]);
+        const uint32_t e = (uint32_t) __builtin_amdgcn_readfirstlane((int) ~hbounds[n_reads + r]);
+        if (s >= e || e > n_hits) continue;       // (a read without hits has s = all-ones, e = 0)
+        const uint32_t n = e - s;
+        if (n <= wave_min || n > wave_max || n > sort_long) continue;
+#define SORT_WAVE_CASE(E)                                                                                             \
+    if (n <= 64u * E) {                                                                                               \
+        sort_wave_segment<E>(lane, r, s, n, h_key, h_pos, h_rank, h_rec, s_read, s_key, s_pos, s_rank, s_rec);        \
+        continue;                                                                                                     \
+    }
+        if constexpr (BIG) {
+            if (n <= 64u * 16) continue;
+            SORT_WAVE_CASE(32)
+        } else {
+            SORT_WAVE_CASE(1)
+            SORT_WAVE_CASE(2)
+            SORT_WAVE_CASE(4)
+            SORT_WAVE_CASE(8)
+            SORT_WAVE_CASE(16)
+        }
+#undef SORT_WAVE_CASE
+    }
+    static_assert(SORT_WAVE_E == 32, "one case per power of two up to SORT_WAVE_E");
 }
 
 // ---------------------------------------------------------------------------

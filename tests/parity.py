@@ -63,8 +63,9 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
         variants = (None, "np8", "lds") if w == 14 else (None, "lds")
     for sketch in variants:
         # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
+        # (rank-counting sort for every read: PMAP_FLAG_SORT_NO_WAVE)
         res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, unfused=True,
-                            sketch=sketch)
+                            sketch=sketch, flags=32)
         cn = res.counts()
         assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
         gm = res.minimizers()
@@ -77,9 +78,11 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
         _check_hits_and_clusters(res, cn, orc)
         res.close()
 
-        # default (fused) mode; the sort variant for very wide keys takes turns with the usual one
+        # default (fused) mode; the sort variant for very wide keys takes turns with the usual one, and so does
+        # the wavefront sort for every read it can take (PMAP_FLAG_TEST_SORT_WAVE_ALL) with the default split
+        # between it and the rank counting
         res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, sketch=sketch,
-                            sort_wide=sketch is None)
+                            sort_wide=sketch is None, flags=64 if sketch is None else 0)
         cn = res.counts()
         assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
         _check_hits_and_clusters(res, cn, orc)
