@@ -359,6 +359,41 @@ def test_megabase_reads(gpu):
     assert res.kernel_ms()["sort_rank"] < 20.0
 
 
+def test_wavefront_sort_comes_and_goes(gpu):
+    """Reads of 320 to 2048 hits are sorted by one wavefront each (a network in registers), shorter and longer
+    ones by the other sort kernels; a result object launches that kernel only while its batches hold such reads.
+    One result object over batches with and without them, every hit count from a few to beyond 2048 side by
+    side: same hits and clusters as the oracle each time."""
+    from parity import _check_hits_and_clusters, oracle_index
+    rng = np.random.default_rng(77)
+    loci = synth.make_loci(40, rng, family_frac=0.5, family_max=6)
+    vloci = synth.make_variant_loci(loci, rng)
+    si = synth.build_variant_index(vloci, 14, 15)
+    genome = synth.make_variant_genome(vloci, rng)
+    g2 = np.concatenate([genome, synth.revcomp(genome)])
+    small = [bytes(g2[a:a + n]) for a, n in ((0, 400), (3000, 900), (9000, 1500), (100, 60), (20000, 2000))]
+    mixed = [bytes(g2[a:a + n]) for a, n in ((0, 700), (500, 4000), (2000, 7000), (100, 11000), (7000, 16000),
+                                              (1000, 23000), (300, 30000), (5000, 45000), (0, 250), (4000, 60000))]
+    gidx = gpu_index(si)
+    frac = api.fraction(0.11, 15)
+    res = None
+    seen = set()
+    for reads in (small, mixed, mixed, small, small, mixed):
+        bases, off = O.pack_reads(reads)
+        ids = np.arange(len(reads), dtype=np.uint32)
+        orc = O.oracle_map(oracle_index(si), bases, off, ids, 14, 15, 250, frac, 10, 0xFFFFFFFF, si.min_path_length)
+        per_read = np.bincount(orc["hit_read"], minlength=len(reads))
+        seen.update("small" if n <= 320 else "wave" if n <= 1024 else "wave32" if n <= 2048 else "rank" if n <= 4096
+                    else "long" for n in per_read)
+        rd = api.Reads(bases, off)
+        res = api.map_reads(gidx, rd, 14, 15, 250, frac, result=res)
+        _check_hits_and_clusters(res, res.counts(), orc)
+        rd.close()
+    assert seen == {"small", "wave", "wave32", "rank", "long"}, seen
+    res.close()
+    gidx.close()
+
+
 def test_chained_scan_fallback(gpu):
     """When a chained prefix sum of the cluster kernels gives up waiting, the batch is mapped again with one
     workgroup per kernel that carries the prefix itself; same clusters.  The test hook makes the chain give up
