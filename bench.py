@@ -224,9 +224,10 @@ def other_workload(api, synth, name, scale, depth, budget_s):
     info = wl.gidx.info()
     sk = kernel_ms.get("sketch", 0.0)
     out = {
-        "workload": "%s: %d loci, %d keys, %d records, table %.0f MB, filter bits/key %d; %d reads, w=%d k=%d"
+        "workload": "%s: %d loci, %d keys, %d records, table %.0f MB, filter %s; %d reads, w=%d k=%d"
                     % (name, wl.si.n_prg, info["n_keys"], info["n_recs"], info["table_slots"] * 32 / 1e6,
-                       info["filter_bits_per_key"], cn["n_reads"], wl.prm["w"], wl.prm["k"]),
+                       "key-range bitmap" if info["filter_direct"] else "bits/key %d" % info["filter_bits_per_key"],
+                       cn["n_reads"], wl.prm["w"], wl.prm["k"]),
         "bases_per_s": cn["n_bases"] * steps / elapsed, "hits_per_s": cn["n_hits"] * steps / elapsed,
         "ms_per_step": elapsed / steps * 1e3, "steps": steps, "steps_in_flight": depth,
         "bases": cn["n_bases"], "minimizers": cn["n_minimizers"], "hits": cn["n_hits"],

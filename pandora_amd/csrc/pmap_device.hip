@@ -50,11 +50,12 @@
 // took 0.267 ms.  Hence coverage and clearing share the tail stream.)  Uploads and encodes run on their
 // own stream, so that a batch can be brought in while the kernels of the batch before it run.
 static const int N_SKETCH_STREAMS = 2;
+static int g_tail_streams = getenv("PMAP_TAIL_STREAMS") ? atoi(getenv("PMAP_TAIL_STREAMS")) : 2;
 struct pmap_result;
 struct DevCtx {
     int device = 0;
-    hipStream_t sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, tail = nullptr, upload = nullptr;
-    unsigned sketch_turn = 0;
+    hipStream_t sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, tail = nullptr, tail2 = nullptr, upload = nullptr;
+    unsigned sketch_turn = 0, tail_turn = 0;
     // pmap_map_noalloc: this device's copy of the scratch array, a result object whose buffers are views
     // of it and of the caller's outputs, pinned staging of the per-prg thresholds
     unsigned char *scratch = nullptr;
@@ -126,6 +127,7 @@ static int new_context(int device, DevCtx **out) {
     // on one GPU a low-priority sketch queue that the tail queue waits for was never scheduled
     for (auto &sk : ctx->sketch) HIP_TRY(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
+    if (g_tail_streams > 1) HIP_TRY(hipStreamCreateWithFlags(&ctx->tail2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
     t_ctx = ctx;
     if (int rc = noalloc_setup(ctx)) return rc;
@@ -681,7 +683,8 @@ static int run_pipeline(pmap_result *res) {
     DevCtx *ctx = res->ctx;
     if ((rc = bind(ctx))) return rc;
     const pmap_index::OnDevice &od = idx->dev[ctx->device];
-    hipStream_t g_tail = ctx->tail;
+    // (the kernels after the sketch kernel of successive batches do not depend on each other either)
+    hipStream_t g_tail = ctx->tail2 && (ctx->tail_turn++ & 1u) ? ctx->tail2 : ctx->tail;
     hipStream_t sketch_stream = ctx->sketch[ctx->sketch_turn++ % N_SKETCH_STREAMS];
     g_cur = sketch_stream;
     const uint32_t k = prm->k, w = prm->w;

@@ -20,7 +20,7 @@ import os
 import sys
 
 PHASE_OF = [("sketch_wave", "sketch+probe"), ("sketch_dpp", "sketch+probe"), ("probe_wave", "sketch+probe"), ("scan_", None),
-            ("scatter_group", "emit"), ("group_reduce", "emit"), ("sort_rank", "sort"), ("long_presort", "sort"),
+            ("scatter_group", "emit"), ("group_reduce", "emit"), ("sort_rank", "sort"), ("sort_wave", "sort"), ("long_presort", "sort"),
             ("long_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
 
 
