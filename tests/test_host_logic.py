@@ -215,6 +215,35 @@ def test_index_binary_cache(tmp_path):
     assert api.Index.load_cached(txt, 11, mpl2, cache)[1]
 
 
+def test_presence_filter_choice(tmp_path, monkeypatch):
+    """Which presence filter an index gets: a hashed bitmap of at most 2^24 bits while the keys are few enough
+    for it (one bit per key, two on denser indexes); beyond that, for k <= 15, a bitmap over the whole key range
+    when the keys crowd the low end of the range as window minima do (w = 14), none when they are spread evenly
+    (w = 1); the bitmap survives the binary cache."""
+    rng = np.random.default_rng(9)
+    loci = [synth.random_dna(3000, rng) for _ in range(12)]
+    si14 = synth.build_index(loci, 14, 15)
+    si1 = synth.build_index(loci, 1, 15)
+
+    def info(si):
+        idx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                               si.iv_start, si.iv_len, si.min_path_length)
+        i = idx.info()
+        return idx, (i["filter_bits"], i["filter_bits_per_key"], i["filter_direct"])
+
+    assert info(si14)[1][1:] == (1, 0)                    # few keys: hashed, one bit per key
+    monkeypatch.setenv("PMAP_FILTER_MAX_BITS", "12")      # as if the keys outnumbered what a hashed filter takes
+    idx, got = info(si14)
+    assert got == (30, 1, 1)
+    assert info(si1)[1] == (0, 0, 0)
+    monkeypatch.setenv("PMAP_FILTER_DIRECT", "0")
+    assert info(si14)[1] == (0, 0, 0)
+    cache = tmp_path / "direct.cache"
+    idx.save_cache(cache)
+    i = api.Index.load_cache(cache).info()
+    assert (i["filter_bits"], i["filter_bits_per_key"], i["filter_direct"]) == (30, 1, 1)
+
+
 def test_gfa_min_path_length(tmp_path):
     cases = list(RC.BIGGER_INFER["graphs"].values()) + list(RC.SIMPLE_INFER["graphs"].values())
     for i, (paths, edges) in enumerate(cases):
