@@ -242,7 +242,24 @@ def other_workload(api, synth, name, scale, depth, budget_s):
             r.close()
     wl.close()
     out["setup_s"] = time.perf_counter() - t0 - elapsed
+    out.update(step_traffic(name, out["ms_per_step"]))
     return out
+
+
+def step_traffic(name, ms_per_step):
+    """HBM-side bytes of one step of a workload (all phases) from the committed PMC passes, against this run's step
+    time: what the memory system moves per second while the workload runs, wasted parts of 128-byte lines included."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(pmc)).get(name)
+    except Exception:
+        rec = None
+    if not rec or ms_per_step <= 0:
+        return {}
+    total = sum(rec.get(p, 0.0) for p in PHASES)
+    return {"step_traffic": {"bytes_per_step": total, "GBps": total / (ms_per_step * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "source": "not measured in this run: " + str(rec.get("source"))}}
 
 
 def main():
@@ -420,6 +437,7 @@ def main():
             "whole_step": {"algorithmic_bytes": total_algo,
                            "GBps": total_algo / (elapsed_local / steps) / 1e9,
                            "frac_of_hbm_peak": total_algo / (elapsed_local / steps) / 1e9 / HBM_PEAK_GBS},
+            **(step_traffic(args.workload, elapsed_local / steps * 1e3) if args.scale == 1.0 else {}),
             "upload_and_encode_s": wl.upload_s,
             "end_to_end": {"note": "one batch from pageable host memory as ASCII: upload + encode + one step",
                            "bases_per_s": cn["n_bases"] / (wl.upload_s + elapsed_local / steps)},

@@ -27,3 +27,6 @@ for path in sys.argv[1:]:
             name, o["bases_per_s"] / 1e9, o["ms_per_step"], o["hits_per_s"], o["lookups_per_s"],
             " ".join("%s %.3f" % (k, v) for k, v in km.items() if v > 0), o["setup_s"]))
         print("   M=%.2e H=%.2e C=%.2e  %s" % (o["minimizers"], o["hits"], o["clusters_all"], o["workload"]))
+        if o.get("step_traffic"):
+            print("   memory traffic of a step (PMC passes): %.0f MB -> %.0f GB/s, %.2f of the HBM peak" % (
+                o["step_traffic"]["bytes_per_step"] / 1e6, o["step_traffic"]["GBps"], o["step_traffic"]["frac_of_hbm_peak"]))
