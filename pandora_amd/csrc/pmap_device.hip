@@ -1224,6 +1224,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
                                              prm->min_cluster_size);
         na.thr_stage[idx->n_prg] = 0;
         HIP_TRY(hipMemcpyAsync(res->thr.p, na.thr_stage, 4 * ((size_t) idx->n_prg + 1), hipMemcpyHostToDevice, g_tail));
+        HIP_TRY(hipStreamSynchronize(g_tail));        // the kernels that read the table may run on the other tail stream
         res->thr_serial = idx->serial;
         res->thr_fraction = prm->fraction;
         res->thr_min = prm->min_cluster_size;

@@ -53,6 +53,11 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
                 r = bytes(arr)
         reads.append(r)
     bases, off = O.pack_reads(reads)
+    # the presence filter in front of the table: the library's choice, none / hashed only, or the key-range bitmap
+    os.environ.pop("PMAP_FILTER_DIRECT", None)
+    mode = int(rng.integers(0, 3))
+    if mode:
+        os.environ["PMAP_FILTER_DIRECT"] = str(mode - 1)
     compare_batch(si, bases, off, w, k, int(rng.integers(1, 300)), api.fraction(float(rng.random()) * 0.2, k),
                   min_cluster_size=int(rng.integers(0, 4)), first_read_id=int(rng.integers(0, 1000)))
     n += 1
