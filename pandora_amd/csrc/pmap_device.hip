@@ -39,18 +39,27 @@
 // different GPUs or on the same one (pmap_init_devices); every reads / result / coverage object belongs to
 // the context it was created in, and calls on it switch the calling thread to that context's GPU.
 //
-// The map path runs on two sketch streams and a tail stream.  The sketch kernels of successive batches
-// alternate between the sketch streams (they do not depend on each other): the second one fills the
+// The map path runs on two sketch streams and one or two tail streams.  The sketch kernels of successive
+// batches alternate between the sketch streams (they do not depend on each other): the second one fills the
 // compute units as the first one drains, and the 15 us between two kernels of one stream (end-of-kernel
 // barrier, event, launch) are hidden behind the other stream.  Everything after the sketch kernel runs on
-// `tail` behind an event: a string of short, latency-bound kernels that now runs next to the sketch
+// a tail stream behind an event: a string of short, latency-bound kernels that now runs next to the sketch
 // kernels of the following batches instead of in front of them.  One step of the reference workload:
-// 0.243 ms as the sum of its kernels, 0.245 ms with one sketch stream, 0.230 ms with two.  (The streams
-// of a process must not outnumber its hardware queues, 4 by default: with a fifth stream the same design
-// took 0.267 ms.  Hence coverage and clearing share the tail stream.)  Uploads and encodes run on their
-// own stream, so that a batch can be brought in while the kernels of the batch before it run.
+// 0.243 ms as the sum of its kernels, 0.245 ms with one sketch stream, 0.230 ms with two.  On workloads
+// with many hits per base that string is longer than a sketch kernel and bounds the step: with two tail
+// streams the strings of successive batches overlap as well (+ 3 to 16 % there).  The streams of a process
+// must not outnumber its hardware queues, though (GPU_MAX_HW_QUEUES, 4 unless the environment says
+// otherwise: with a fifth stream on four queues the reference workload took 0.267 ms), so the second tail
+// stream exists only when the environment grants at least 6 queues (PMAP_TAIL_STREAMS=1|2 overrides), and
+// coverage and clearing share a tail stream.  Uploads and encodes run on their own stream, so that a batch
+// can be brought in while the kernels of the batch before it run.
 static const int N_SKETCH_STREAMS = 2;
-static int g_tail_streams = getenv("PMAP_TAIL_STREAMS") ? atoi(getenv("PMAP_TAIL_STREAMS")) : 2;
+static int default_tail_streams() {
+    if (const char *e = getenv("PMAP_TAIL_STREAMS")) return atoi(e);
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    return q && atoi(q) >= 6 ? 2 : 1;
+}
+static int g_tail_streams = default_tail_streams();
 struct pmap_result;
 struct DevCtx {
     int device = 0;

@@ -466,3 +466,22 @@ print("child ok", first["n_hits"], int(ring[0].counts()["ms"][5]))
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "child ok" in o, o
 
+
+
+def test_two_tail_streams(gpu):
+    """With at least 6 hardware queues granted (GPU_MAX_HW_QUEUES, as bench.py sets it) a mapping context runs the
+    kernels behind the sketch kernel of successive batches on two streams in turn.  The library reads that when it
+    is loaded, so a fresh process runs the tests that keep several batches in flight, reuse result objects and map
+    file after file; same results."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", PMAP_TAIL_STREAMS="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_pangraph.py"),
+           "-k", "async_batches_in_flight or large_segment_and_reuse or nanopore_small or wavefront_sort_comes or "
+                 "contexts_and_parsers or batch_size or coverage"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and " passed" in out, out[-3000:]
