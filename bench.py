@@ -125,10 +125,23 @@ def cpu_baseline(si, bases, offsets, prm, fraction, budget_s=10.0, threads_budge
     return out
 
 
-class Workload:
-    """One synthetic workload resident on the GPU: index, one batch of reads, the call that maps it."""
+def rotated_batch(bases, offsets, shift):
+    """The same reads starting with read `shift` (a different batch in memory with the same per-read results)."""
+    n = len(offsets) - 1
+    if shift % max(n, 1) == 0:
+        return bases, offsets
+    cut = int(offsets[shift % n])
+    lens = np.diff(offsets.astype(np.int64))
+    new_off = np.concatenate([[0], np.cumsum(np.roll(lens, -(shift % n)))]).astype(offsets.dtype)
+    return np.concatenate([bases[cut:], bases[:cut]]), new_off
 
-    def __init__(self, api, synth, name, scale, shard, last_stage=0):
+
+class Workload:
+    """One synthetic workload resident on the GPU: index, `n_batches` batches of reads (the same reads in rotated
+    order: steps take the batches in turn, so that what a step reads was last touched n_batches steps ago and the
+    batches together exceed the 256 MB Infinity Cache), the call that maps one."""
+
+    def __init__(self, api, synth, name, scale, shard, last_stage=0, n_batches=1):
         self.api, self.name = api, name
         self.si, self.bases, self.offsets, self.prm = synth.workload(name, seed=1, scale=scale, shard=shard)
         si, prm = self.si, self.prm
@@ -141,15 +154,24 @@ class Workload:
         t0 = time.perf_counter()
         self.reads = api.Reads(self.bases, self.offsets)
         self.upload_s = time.perf_counter() - t0
+        n_reads = len(self.offsets) - 1
+        self.batches = [self.reads]
+        for j in range(1, max(1, n_batches)):
+            b, o = rotated_batch(self.bases, self.offsets, j * n_reads // n_batches)
+            self.batches.append(api.Reads(b, o))
+        self.turn = 0
 
     def step(self, res, profile, wait=True):
         p = self.prm
-        return self.api.map_reads(self.gidx, self.reads, p["w"], p["k"], p["max_diff"], self.fraction,
+        reads = self.batches[self.turn % len(self.batches)]
+        self.turn += 1
+        return self.api.map_reads(self.gidx, reads, p["w"], p["k"], p["max_diff"], self.fraction,
                                   p["min_cluster_size"], self.expected, profile=profile, result=res, wait=wait,
                                   last_stage=self.last_stage)
 
     def close(self):
-        self.reads.close()
+        for r in self.batches:
+            r.close()
         self.gidx.close()
 
 
@@ -208,10 +230,10 @@ def phase_table(kernel_ms, algo):
     return phases
 
 
-def other_workload(api, synth, name, scale, depth, budget_s):
+def other_workload(api, synth, name, scale, depth, budget_s, n_batches=1):
     """Throughput and per-kernel table of one more workload (N = 1 only)."""
     t0 = time.perf_counter()
-    wl = Workload(api, synth, name, scale, 0)
+    wl = Workload(api, synth, name, scale, 0, n_batches=n_batches)
     ring = [None] * depth
     for i in range(max(3, depth)):
         ring[i % depth] = wl.step(ring[i % depth], 0)
@@ -229,7 +251,7 @@ def other_workload(api, synth, name, scale, depth, budget_s):
                        "key-range bitmap" if info["filter_direct"] else "bits/key %d" % info["filter_bits_per_key"],
                        cn["n_reads"], wl.prm["w"], wl.prm["k"]),
         "bases_per_s": cn["n_bases"] * steps / elapsed, "hits_per_s": cn["n_hits"] * steps / elapsed,
-        "ms_per_step": elapsed / steps * 1e3, "steps": steps, "steps_in_flight": depth,
+        "ms_per_step": elapsed / steps * 1e3, "steps": steps, "steps_in_flight": depth, "resident_batches": n_batches,
         "bases": cn["n_bases"], "minimizers": cn["n_minimizers"], "hits": cn["n_hits"],
         "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],
         "kernel_ms_alone": kernel_ms, "phases": phase_table(kernel_ms, algo),
@@ -277,6 +299,9 @@ def main():
                          "nanopore_1k_linear, nanopore_1k_families, illumina_1k, illumina_w1, nanopore_20k, "
                          "illumina_20k_w1, nanopore_200k while the time budget lasts)")
     ap.add_argument("--others-budget", type=float, default=240.0, help="seconds the other workloads may take in all")
+    ap.add_argument("--resident-batches", type=int, default=6,
+                    help="batches of reads kept on the GPU and mapped in turn (the same reads in rotated order): with "
+                         "one, a step re-reads what the step before left in the 256 MB Infinity Cache")
     ap.add_argument("--depth", type=int, default=3,
                     help="steps in flight (1 = blocking pmap_map); with 3 both sketch streams always hold a kernel "
                          "while the host waits for a result, and the tail kernels of a step run next to the sketch "
@@ -328,7 +353,7 @@ def main():
     t_start = time.perf_counter()
     progress("synthesising workload %s" % args.workload)
     # same index on every rank (replicated), a different shard of reads per rank
-    wl = Workload(api, synth, args.workload, args.scale, rank, args.last_stage)
+    wl = Workload(api, synth, args.workload, args.scale, rank, args.last_stage, n_batches=args.resident_batches)
     si, prm = wl.si, wl.prm
     progress("index (%d keys, %d records) and %d bases on the device" % (len(si.keys), len(si.rec_prg), len(wl.bases)))
 
@@ -430,7 +455,7 @@ def main():
                        "index_keys": int(len(si.keys)), "index_records": int(len(si.rec_prg)),
                        "index_intervals": int(len(si.iv_start)),
                        "parallelism": "reads sharded over %d GPU(s), index replicated" % world,
-                       "steps_in_flight": depth},
+                       "steps_in_flight": depth, "resident_batches": args.resident_batches},
             "hits_per_s": total_hits * args.steps / elapsed,
             "roofline": roofline,
             "phases": phases,
@@ -465,7 +490,7 @@ def main():
                 continue
             progress("other workload %s" % name)
             try:
-                others[name] = other_workload(api, synth, name, 1.0, depth, 0.5)
+                others[name] = other_workload(api, synth, name, 1.0, depth, 0.5, args.resident_batches)
             except Exception as e:      # a side measurement must not lose the headline line
                 others[name] = "failed: %r" % (e,)
         if names:
