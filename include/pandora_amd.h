@@ -183,7 +183,7 @@ typedef struct {
 /* Diagnostic: sort with the kernel variant for indexes of more than 2^19 loci (keys too wide to share a
  * word with a position) whatever the index. */
 #define PMAP_FLAG_SORT_WIDE 8u
-/* Diagnostic: reads of middling hit counts (320 < hits <= 2048 by default; PMAP_SORT_WAVE_MIN / _MAX, read
+/* Diagnostic: reads of middling hit counts (more than 192 hits, 320 with w < 8, and at most 2048 by default; PMAP_SORT_WAVE_MIN / _MAX, read
  * by pmap_init) are sorted by one wavefront each with a network in registers; with PMAP_FLAG_SORT_NO_WAVE they
  * take the rank-counting sort like shorter reads, with PMAP_FLAG_TEST_SORT_WAVE_ALL every read of 2 to 2048
  * hits takes the wavefront sort.  Results are the same. */

@@ -85,7 +85,9 @@ static SketchKind g_sketch_pref = SKETCH_DPP16;
 static uint32_t g_sort_long = 4096;
 // reads with more than g_sort_wave_min and at most g_sort_wave_max hits: sort_wave_kernel (one wavefront per read)
 static const uint32_t SORT_WAVE_LIMIT = 2048;      // = 64 * SORT_WAVE_E of the kernel
-static uint32_t g_sort_wave_min = 320, g_sort_wave_max = SORT_WAVE_LIMIT;
+// (PMAP_SORT_WAVE_MIN / _MAX override; by default the lower bound is 192 for sparse sketches, w >= 8, and 320 for
+// dense ones, whose batches of very many short reads are bound by memory traffic rather than by instructions)
+static uint32_t g_sort_wave_min = 0, g_sort_wave_max = SORT_WAVE_LIMIT;
 
 // ---------------------------------------------------------------------------
 // Scratch memory of pmap_map_noalloc, the entry point that allocates nothing: everything pmap_map keeps
@@ -159,7 +161,7 @@ extern "C" int pmap_init(int device) {
     const char *sk = getenv("PMAP_SKETCH");
     g_sketch_pref = sk && !strcmp(sk, "lds") ? SKETCH_LDS : sk && !strcmp(sk, "np8") ? SKETCH_DPP8 : SKETCH_DPP16;
     if (const char *sl = getenv("PMAP_SORT_LONG")) g_sort_long = (uint32_t) std::max(1, atoi(sl));
-    if (const char *sw = getenv("PMAP_SORT_WAVE_MIN")) g_sort_wave_min = (uint32_t) std::max(0, atoi(sw));
+    if (const char *sw = getenv("PMAP_SORT_WAVE_MIN")) g_sort_wave_min = (uint32_t) std::max(1, atoi(sw));
     if (const char *sw = getenv("PMAP_SORT_WAVE_MAX")) g_sort_wave_max = (uint32_t) std::min((int) SORT_WAVE_LIMIT, std::max(0, atoi(sw)));
     if (device < 0) {
         if (t_ctx) return PMAP_OK;
@@ -833,7 +835,7 @@ static int run_pipeline(pmap_result *res) {
         // Reads of middling hit counts go to sort_wave_kernel, whose words hold a key and a place of up to
         // 6 + log2 SORT_WAVE_E bits (PMAP_FLAG_SORT_NO_WAVE: none do; PMAP_FLAG_TEST_SORT_WAVE_ALL: every read
         // of 2 hits or more up to the kernel's limit does)
-        uint32_t wave_min = g_sort_wave_min, wave_max = g_sort_wave_max;
+        uint32_t wave_min = g_sort_wave_min ? g_sort_wave_min : w >= 8 ? 192u : 320u, wave_max = g_sort_wave_max;
         uint32_t *wave_list = res->hbounds.as<uint32_t>() + 2 * ((size_t) rd->n_reads + 1);     // behind the bounds
         if (prm->flags & PMAP_FLAG_TEST_SORT_WAVE_ALL) wave_min = 1, wave_max = SORT_WAVE_LIMIT;
         // (a read has at most one minimizer per base and a minimizer at most max_cnt hits)

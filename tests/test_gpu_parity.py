@@ -360,7 +360,7 @@ def test_megabase_reads(gpu):
 
 
 def test_wavefront_sort_comes_and_goes(gpu):
-    """Reads of 320 to 2048 hits are sorted by one wavefront each (a network in registers), shorter and longer
+    """Reads of 193 to 2048 hits are sorted by one wavefront each (a network in registers), shorter and longer
     ones by the other sort kernels; a result object launches that kernel only while its batches hold such reads.
     One result object over batches with and without them, every hit count from a few to beyond 2048 side by
     side: same hits and clusters as the oracle each time."""
@@ -383,7 +383,7 @@ def test_wavefront_sort_comes_and_goes(gpu):
         ids = np.arange(len(reads), dtype=np.uint32)
         orc = O.oracle_map(oracle_index(si), bases, off, ids, 14, 15, 250, frac, 10, 0xFFFFFFFF, si.min_path_length)
         per_read = np.bincount(orc["hit_read"], minlength=len(reads))
-        seen.update("small" if n <= 320 else "wave" if n <= 1024 else "wave32" if n <= 2048 else "rank" if n <= 4096
+        seen.update("small" if n <= 192 else "wave" if n <= 1024 else "wave32" if n <= 2048 else "rank" if n <= 4096
                     else "long" for n in per_read)
         rd = api.Reads(bases, off)
         res = api.map_reads(gidx, rd, 14, 15, 250, frac, result=res)
