@@ -335,6 +335,8 @@ struct PgRead {
 struct pmap_pangraph {
     std::map<uint32_t, uint32_t> node_covg;   // node id (= prg id) -> covg
     std::map<uint32_t, PgRead> reads;
+    PgRead *last_read = nullptr;      // the entry of `last_read_id` (map nodes do not move): calls come grouped by read
+    uint32_t last_read_id = 0;
     HitBuf hits;                      // in add_node call order, each call's cluster in pComp order
     std::vector<uint32_t> call_prg, call_read, call_size;
     std::vector<uint8_t> call_fwd;
@@ -350,7 +352,12 @@ struct pmap_pangraph {
 static void pg_add_node(pmap_pangraph *pg, uint32_t prg, uint32_t read, uint32_t size, bool first_fwd) {
     auto it = pg->node_covg.find(prg);
     if (it == pg->node_covg.end()) pg->node_covg[prg] = 1; else it->second += 1;
-    PgRead &r = pg->reads[read];
+    // (read ids arrive in rising order, one read's calls together: the entry is the last one used or a new last one)
+    if (!pg->last_read || pg->last_read_id != read) {
+        pg->last_read = &pg->reads.emplace_hint(pg->reads.end(), read, PgRead())->second;
+        pg->last_read_id = read;
+    }
+    PgRead &r = *pg->last_read;
     const uint8_t orientation = size > 0 && first_fwd;
     if (r.nodes.empty() || r.nodes.back() != prg || r.orient.back() != orientation) {
         r.nodes.push_back(prg);
