@@ -56,7 +56,7 @@ int pmap_init(int device);
  * read file over: one per entry of `devices`, in this order; a GPU may be
  * listed more than once (two contexts on one GPU overlap the upload of one
  * batch with the kernels and the host work of another).  n = 0 goes back to
- * the default, two contexts on the calling thread's GPU.  No counterpart in
+ * the default, three contexts on the calling thread's GPU.  No counterpart in
  * the reference, which is single-threaded: results do not depend on it. */
 int pmap_init_devices(const int *devices, int n);
 

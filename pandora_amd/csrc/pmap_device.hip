@@ -225,20 +225,24 @@ int pmap_contexts_for_file(std::vector<void *> *out) {
         for (DevCtx *c : g_pool) out->push_back(c);
     }
     if (!out->empty()) return PMAP_OK;
-    DevCtx *mine = t_ctx, *second = nullptr;
+    // no list from pmap_init_devices: FILE_CONTEXTS contexts on the calling thread's GPU, its own among them (two
+    // mapper threads are busy 90 % of the time at 15 Gbases/s of FASTQ; with three the parser threads are the limit)
+    static const size_t FILE_CONTEXTS = 3;
+    DevCtx *mine = t_ctx;
+    out->push_back(mine);
     {
         std::lock_guard<std::mutex> l(g_ctx_mu);
         for (DevCtx *c : g_all_ctx)
-            if (c->device == mine->device && c != mine) { second = c; break; }
+            if (c->device == mine->device && c != mine && out->size() < FILE_CONTEXTS) out->push_back(c);
     }
-    if (!second) {
-        rc = new_context(mine->device, &second);
+    while (out->size() < FILE_CONTEXTS) {
+        DevCtx *more = nullptr;
+        rc = new_context(mine->device, &more);
         t_ctx = nullptr;
         if (int rb = bind(mine)) return rb;
         if (rc) return rc;
+        out->push_back(more);
     }
-    out->push_back(mine);
-    out->push_back(second);
     return PMAP_OK;
 }
 

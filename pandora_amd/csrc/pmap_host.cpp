@@ -398,7 +398,7 @@ static void pg_sort_hits(pmap_pangraph *pg) {
 //   sequence  one thread takes the pieces in file order, checks that every seam really was a record
 //             boundary (else the two pieces are parsed again as one), and applies the read loop's rules
 //             (read ids, coverage stop, 10M-read stop, Illumina k-mer count; src/utils.cpp:397-440).
-//   map       one thread per mapping context (pmap_init_devices; by default two on the caller's GPU):
+//   map       one thread per mapping context (pmap_init_devices; by default three on the caller's GPU):
 //             upload, kernels, results back, filter_clusters, coverage - whole batches, in any order.
 //   retire    the calling thread performs the add_node calls batch by batch in file order.
 

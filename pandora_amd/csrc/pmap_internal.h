@@ -117,7 +117,7 @@ int pmap_index_upload(pmap_index *idx);          // to the calling thread's curr
 void pmap_index_release_device(pmap_index *idx);
 
 // The mapping contexts (opaque) pmap_pangraph_from_read_file spreads its batches over: those of
-// pmap_init_devices, or two on the calling thread's GPU.  pmap_bind_context makes one of them the calling
+// pmap_init_devices, or three on the calling thread's GPU.  pmap_bind_context makes one of them the calling
 // thread's current context.
 int pmap_contexts_for_file(std::vector<void *> *out);
 int pmap_bind_context(void *ctx);
