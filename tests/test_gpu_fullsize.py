@@ -122,3 +122,65 @@ def test_big_index_slice_against_oracle(gpu):
                           gidx=gidx)
     assert cn["n_minimizers"] > 300000
     gidx.close()
+
+
+def test_illumina_w1_full_size(gpu):
+    """BASELINE's Illumina configuration at the bench's full size (200 000 reads of 150 bases, w = 1: every k-mer is
+    looked up, 13 M hits): hit order, record and cluster invariants over the whole batch, the batch in three
+    uneven pieces against the single batch, and slices of it stage by stage against the oracle."""
+    si, bases, off, prm = synth.workload("illumina_w1", seed=1)
+    gidx = gpu_index(si)
+    frac = api.fraction(prm["e_rate"], prm["k"])
+    expected = 150 * 2 // prm["w"]
+    rd = api.Reads(bases, off)
+    res = api.map_reads(gidx, rd, prm["w"], prm["k"], prm["max_diff"], frac, prm["min_cluster_size"], expected)
+    cn, h, c = res.counts(), res.hits(), res.clusters()
+    assert cn["n_reads"] == 200000 and cn["n_minimizers"] > 2.5e7 and cn["n_hits"] > 1e7
+    coarse = (h["read"].astype(np.int64) << 44) | (h["prg"].astype(np.int64) << 33) | \
+             ((1 - h["fwd"].astype(np.int64)) << 32) | h["pos"].astype(np.int64)
+    assert (np.diff(coarse) >= 0).all()
+    assert (h["prg"] == si.rec_prg[h["rec"]]).all() and h["pos"].max() <= 150 - prm["k"]
+    b, s = c["begin"].astype(np.int64), c["size"].astype(np.int64)
+    if len(b):
+        assert (np.diff(b) > 0).all() and (b[:-1] + s[:-1] <= b[1:]).all() and b[-1] + s[-1] <= cn["n_hits"]
+        last = b + s - 1
+        for f, g in (("read", "read"), ("prg", "prg"), ("fwd", "fwd")):
+            assert (h[f][b] == c[g]).all() and (h[f][last] == c[g]).all()
+        thr = np.maximum((np.minimum(si.min_path_length, expected).astype(np.float32) * np.float32(frac)).astype(np.uint32),
+                         prm["min_cluster_size"])
+        assert (c["size"] > thr[c["prg"]]).all()
+    # three uneven pieces with one result object
+    n = len(off) - 1
+    cuts = [0, n // 9, n // 2 + 5, n]
+    pieces_h = {f: [] for f in h}
+    pieces_c = {f: [] for f in c}
+    base_hit, r2 = 0, None
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        sub = api.Reads(bases[int(off[a]):int(off[e])], off[a:e + 1] - off[a], first_read_id=a)
+        r2 = api.map_reads(gidx, sub, prm["w"], prm["k"], prm["max_diff"], frac, prm["min_cluster_size"], expected, result=r2)
+        hh, cc = r2.hits(), r2.clusters()
+        for f in pieces_h:
+            pieces_h[f].append(hh[f])
+        cc["begin"] = cc["begin"] + base_hit
+        for f in pieces_c:
+            pieces_c[f].append(cc[f])
+        base_hit += len(hh["read"])
+        sub.close()
+    r2.close()
+    for f in pieces_h:
+        np.testing.assert_array_equal(np.concatenate(pieces_h[f]), h[f], err_msg=f)
+    for f in pieces_c:
+        np.testing.assert_array_equal(np.concatenate(pieces_c[f]), c[f], err_msg=f)
+    # slices against the oracle, and their rows inside the full-batch result
+    for first, count in ((0, 1200), (123456, 1200)):
+        sub_off = off[first:first + count + 1]
+        sub = bases[int(sub_off[0]):int(sub_off[-1])]
+        cns, orc = compare_batch(si, sub, sub_off - sub_off[0], prm["w"], prm["k"], prm["max_diff"], frac,
+                                 prm["min_cluster_size"], expected_kmers=expected, first_read_id=first, gidx=gidx)
+        sel = (h["read"] >= first) & (h["read"] < first + count)
+        assert sel.sum() == cns["n_hits"] > 10000
+        np.testing.assert_array_equal(h["pos"][sel], orc["hit_pos"])
+        np.testing.assert_array_equal(h["rec"][sel], orc["hit_rec"])
+    res.close()
+    rd.close()
+    gidx.close()
