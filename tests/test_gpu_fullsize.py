@@ -124,28 +124,28 @@ def test_big_index_slice_against_oracle(gpu):
     gidx.close()
 
 
-def test_illumina_w1_full_size(gpu):
-    """BASELINE's Illumina configuration at the bench's full size (200 000 reads of 150 bases, w = 1: every k-mer is
-    looked up, 13 M hits): hit order, record and cluster invariants over the whole batch, the batch in three
-    uneven pieces against the single batch, and slices of it stage by stage against the oracle."""
-    si, bases, off, prm = synth.workload("illumina_w1", seed=1)
+def _check_full_size(name, slices, min_reads, min_minimizers, min_hits):
+    """One bench workload at its full size: hit order, record and cluster invariants over the whole batch, the batch
+    in three uneven pieces against the single batch, and slices of it stage by stage against the oracle."""
+    si, bases, off, prm = synth.workload(name, seed=1)
     gidx = gpu_index(si)
     frac = api.fraction(prm["e_rate"], prm["k"])
-    expected = 150 * 2 // prm["w"]
+    expected = 150 * 2 // prm["w"] if prm["illumina"] else 0xFFFFFFFF
     rd = api.Reads(bases, off)
     res = api.map_reads(gidx, rd, prm["w"], prm["k"], prm["max_diff"], frac, prm["min_cluster_size"], expected)
     cn, h, c = res.counts(), res.hits(), res.clusters()
-    assert cn["n_reads"] == 200000 and cn["n_minimizers"] > 2.5e7 and cn["n_hits"] > 1e7
-    coarse = (h["read"].astype(np.int64) << 44) | (h["prg"].astype(np.int64) << 33) | \
-             ((1 - h["fwd"].astype(np.int64)) << 32) | h["pos"].astype(np.int64)
+    assert cn["n_reads"] >= min_reads and cn["n_minimizers"] > min_minimizers and cn["n_hits"] > min_hits
+    assert h["prg"].max() < (1 << 19) and h["read"].max() < (1 << 19) and h["pos"].max() < (1 << 24)
+    coarse = (h["read"].astype(np.int64) << 44) | (h["prg"].astype(np.int64) << 25) | \
+             ((1 - h["fwd"].astype(np.int64)) << 24) | h["pos"].astype(np.int64)
     assert (np.diff(coarse) >= 0).all()
-    assert (h["prg"] == si.rec_prg[h["rec"]]).all() and h["pos"].max() <= 150 - prm["k"]
+    assert (h["prg"] == si.rec_prg[h["rec"]]).all()
     b, s = c["begin"].astype(np.int64), c["size"].astype(np.int64)
     if len(b):
         assert (np.diff(b) > 0).all() and (b[:-1] + s[:-1] <= b[1:]).all() and b[-1] + s[-1] <= cn["n_hits"]
         last = b + s - 1
-        for f, g in (("read", "read"), ("prg", "prg"), ("fwd", "fwd")):
-            assert (h[f][b] == c[g]).all() and (h[f][last] == c[g]).all()
+        for f in ("read", "prg", "fwd"):
+            assert (h[f][b] == c[f]).all() and (h[f][last] == c[f]).all()
         thr = np.maximum((np.minimum(si.min_path_length, expected).astype(np.float32) * np.float32(frac)).astype(np.uint32),
                          prm["min_cluster_size"])
         assert (c["size"] > thr[c["prg"]]).all()
@@ -172,7 +172,7 @@ def test_illumina_w1_full_size(gpu):
     for f in pieces_c:
         np.testing.assert_array_equal(np.concatenate(pieces_c[f]), c[f], err_msg=f)
     # slices against the oracle, and their rows inside the full-batch result
-    for first, count in ((0, 1200), (123456, 1200)):
+    for first, count in slices:
         sub_off = off[first:first + count + 1]
         sub = bases[int(sub_off[0]):int(sub_off[-1])]
         cns, orc = compare_batch(si, sub, sub_off - sub_off[0], prm["w"], prm["k"], prm["max_diff"], frac,
@@ -184,3 +184,15 @@ def test_illumina_w1_full_size(gpu):
     res.close()
     rd.close()
     gidx.close()
+
+
+def test_illumina_w1_full_size(gpu):
+    """BASELINE's Illumina configuration at the bench's full size: 200 000 reads of 150 bases, w = 1 (every k-mer is
+    looked up), 13 M hits."""
+    _check_full_size("illumina_w1", ((0, 1200), (123456, 1200)), 200000, 2.5e7, 1e7)
+
+
+def test_200k_locus_full_size(gpu):
+    """The 200 000-locus index (2 GB table behind the key-range bitmap) with its full batch: 15 000 nanopore reads,
+    7 M hits in 5 M clusters before the size threshold, reads of every hit-count class of the sort."""
+    _check_full_size("nanopore_200k", ((0, 60), (9000, 60)), 15000, 1.5e7, 5e6)
