@@ -289,9 +289,10 @@ extern "C" int pmap_read_fastaq_pieces(const char *path, uint64_t piece_bytes, c
 // ---------------------------------------------------------------------------
 // pangenome::Graph summary
 
+// One hit of Read::hits: position in the read, record, path rank of the record.  Read, prg and strand are those of
+// the add_node call the hit came in with (all hits of a cluster share them): the call arrays hold them once.
 struct PgHit {
-    uint32_t read, prg, pos, rec, rank;
-    uint8_t fwd;
+    uint32_t pos, rec, rank;
 };
 
 // Growing array of hits: realloc moves big blocks by remapping their pages instead of copying them
@@ -342,6 +343,7 @@ struct pmap_pangraph {
     std::vector<uint8_t> call_fwd;
     bool keep_hits = true;
     std::vector<uint64_t> by_path;    // hits in Read::hits order (indices into `hits`), built on demand
+    std::vector<uint32_t> hit_call;   // the call of every hit, built with by_path
     bool by_path_valid = false;
     bool has_cov = false;             // PMAP_PG_COVERAGE: kmer node coverage, summed over the mapping contexts
     std::vector<uint32_t> cov_fwd, cov_rev;
@@ -371,17 +373,30 @@ static void pg_add_node(pmap_pangraph *pg, uint32_t prg, uint32_t read, uint32_t
 
 static void pg_sort_hits(pmap_pangraph *pg) {
     if (pg->by_path_valid) return;
+    // the call every hit belongs to: call j owns the next call_size[j] hits
+    pg->hit_call.resize(pg->hits.size());
+    {
+        size_t o = 0;
+        for (size_t j = 0; j < pg->call_size.size() && o < pg->hit_call.size(); ++j) {
+            const size_t e = std::min(pg->hit_call.size(), o + pg->call_size[j]);
+            std::fill(pg->hit_call.begin() + o, pg->hit_call.begin() + e, (uint32_t) j);
+            o = e;
+        }
+    }
     // per (read, prg): pComp_path (src/minihits.cpp:77-93): path, forward first, position.  The hits themselves
     // stay in call order (pmap_pangraph_call_hits); this is an index into them.
     pg->by_path.resize(pg->hits.size());
     std::iota(pg->by_path.begin(), pg->by_path.end(), 0ull);
     const PgHit *h = pg->hits.p;
-    std::sort(pg->by_path.begin(), pg->by_path.end(), [h](uint64_t x, uint64_t y) {
+    const uint32_t *hc = pg->hit_call.data(), *cread = pg->call_read.data(), *cprg = pg->call_prg.data();
+    const uint8_t *cfwd = pg->call_fwd.data();
+    std::sort(pg->by_path.begin(), pg->by_path.end(), [=](uint64_t x, uint64_t y) {
         const PgHit &a = h[x], &b = h[y];
-        if (a.read != b.read) return a.read < b.read;
-        if (a.prg != b.prg) return a.prg < b.prg;
+        const uint32_t ca = hc[x], cb = hc[y];
+        if (cread[ca] != cread[cb]) return cread[ca] < cread[cb];
+        if (cprg[ca] != cprg[cb]) return cprg[ca] < cprg[cb];
         if (a.rank != b.rank) return a.rank < b.rank;
-        if (a.fwd != b.fwd) return a.fwd > b.fwd;
+        if (cfwd[ca] != cfwd[cb]) return cfwd[ca] > cfwd[cb];
         if (a.pos != b.pos) return a.pos < b.pos;
         return x < y;
     });
@@ -989,7 +1004,7 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool
         out->fwd.push_back(fwd[c]);
         if (keep_hits)
             for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
-                out->hits.push_back(PgHit{rid[c], prg[c], hpos[i], hrec[i], idx->path_rank[hrec[i]], fwd[c]});
+                out->hits.push_back(PgHit{hpos[i], hrec[i], idx->path_rank[hrec[i]]});
     }
     if (cov) {
         // add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383) walks Node::reads, a multiset that
@@ -1275,11 +1290,12 @@ extern "C" int pmap_pangraph_hits(const pmap_pangraph_t *pgc, uint32_t *read_id,
     pg_sort_hits(pg);
     for (size_t i = 0; i < pg->hits.size(); ++i) {
         const PgHit &h = pg->hits[pg->by_path[i]];
-        if (read_id) read_id[i] = h.read;
-        if (prg_id) prg_id[i] = h.prg;
+        const uint32_t call = pg->hit_call[pg->by_path[i]];
+        if (read_id) read_id[i] = pg->call_read[call];
+        if (prg_id) prg_id[i] = pg->call_prg[call];
         if (pos) pos[i] = h.pos;
         if (rec) rec[i] = h.rec;
-        if (is_forward) is_forward[i] = h.fwd;
+        if (is_forward) is_forward[i] = pg->call_fwd[call];
     }
     return PMAP_OK;
 }
