@@ -1254,7 +1254,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     // as pmap_map_wait: the batch is mapped again without a chain between workgroups when a chained prefix sum
     // gave up, with the kernel for tiles full of minimizers when the usual one left a tile out, with the
     // long-segment sort kernels when a read had more hits than the rank counting takes
-    for (int attempt = 0;; ++attempt) {
+    for (;;) {
         if ((rc = run_pipeline(res))) { res->serial_scans = false; return rc; }
         HIP_TRY(hipEventSynchronize(res->done));
         if (res->hc->fail) {

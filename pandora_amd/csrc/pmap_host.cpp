@@ -295,39 +295,6 @@ struct PgHit {
     uint32_t pos, rec, rank;
 };
 
-// Growing array of hits: realloc moves big blocks by remapping their pages instead of copying them
-// (a std::vector of several hundred MB copies itself at every growth step), and the block asks for
-// huge pages so that filling it does not take a page fault per 4 KiB.
-struct HitBuf {
-    PgHit *p = nullptr;
-    size_t n = 0, cap = 0;
-    HitBuf() = default;
-    HitBuf(const HitBuf &) = delete;
-    HitBuf &operator=(const HitBuf &) = delete;
-    ~HitBuf() { free(p); }
-    size_t size() const { return n; }
-    PgHit *begin() { return p; }
-    PgHit *end() { return p + n; }
-    const PgHit &operator[](size_t i) const { return p[i]; }
-    bool reserve_more(size_t extra) {
-        if (n + extra <= cap) return true;
-        size_t ncap = std::max<size_t>(n + extra, cap + cap / 2 + 4096);
-        PgHit *q = (PgHit *) realloc(p, ncap * sizeof(PgHit));
-        if (!q) return false;
-        p = q;
-        cap = ncap;
-#ifdef MADV_HUGEPAGE
-        if (ncap * sizeof(PgHit) >= (size_t) 4 << 20) {
-            const uintptr_t a = ((uintptr_t) p + 4095) & ~(uintptr_t) 4095;
-            const uintptr_t e = ((uintptr_t) p + ncap * sizeof(PgHit)) & ~(uintptr_t) 4095;
-            if (e > a) (void) madvise((void *) a, e - a, MADV_HUGEPAGE);
-        }
-#endif
-        return true;
-    }
-    void push_unchecked(const PgHit &h) { p[n++] = h; }
-};
-
 struct PgRead {
     std::vector<uint32_t> nodes;
     std::vector<uint8_t> orient;
@@ -338,7 +305,13 @@ struct pmap_pangraph {
     std::map<uint32_t, PgRead> reads;
     PgRead *last_read = nullptr;      // the entry of `last_read_id` (map nodes do not move): calls come grouped by read
     uint32_t last_read_id = 0;
-    HitBuf hits;                      // in add_node call order, each call's cluster in pComp order
+    // Read::hits in add_node call order, each call's cluster in pComp order: one segment per mapped batch, kept as
+    // the mapper thread made it (copying 10^7 records once more on the retiring thread made that thread the slow
+    // one); `flat` = the segments in one array, made when hits are asked for by global index
+    std::vector<std::vector<PgHit>> hit_seg;
+    size_t n_hits = 0;
+    std::vector<PgHit> flat;
+    bool flat_valid = false;
     std::vector<uint32_t> call_prg, call_read, call_size;
     std::vector<uint8_t> call_fwd;
     bool keep_hits = true;
@@ -371,10 +344,19 @@ static void pg_add_node(pmap_pangraph *pg, uint32_t prg, uint32_t read, uint32_t
     pg->call_fwd.push_back(first_fwd);
 }
 
+static void pg_flatten_hits(pmap_pangraph *pg) {
+    if (pg->flat_valid) return;
+    pg->flat.clear();
+    pg->flat.reserve(pg->n_hits);
+    for (const auto &seg : pg->hit_seg) pg->flat.insert(pg->flat.end(), seg.begin(), seg.end());
+    pg->flat_valid = true;
+}
+
 static void pg_sort_hits(pmap_pangraph *pg) {
     if (pg->by_path_valid) return;
+    pg_flatten_hits(pg);
     // the call every hit belongs to: call j owns the next call_size[j] hits
-    pg->hit_call.resize(pg->hits.size());
+    pg->hit_call.resize(pg->n_hits);
     {
         size_t o = 0;
         for (size_t j = 0; j < pg->call_size.size() && o < pg->hit_call.size(); ++j) {
@@ -385,9 +367,9 @@ static void pg_sort_hits(pmap_pangraph *pg) {
     }
     // per (read, prg): pComp_path (src/minihits.cpp:77-93): path, forward first, position.  The hits themselves
     // stay in call order (pmap_pangraph_call_hits); this is an index into them.
-    pg->by_path.resize(pg->hits.size());
+    pg->by_path.resize(pg->n_hits);
     std::iota(pg->by_path.begin(), pg->by_path.end(), 0ull);
-    const PgHit *h = pg->hits.p;
+    const PgHit *h = pg->flat.data();
     const uint32_t *hc = pg->hit_call.data(), *cread = pg->call_read.data(), *cprg = pg->call_prg.data();
     const uint8_t *cfwd = pg->call_fwd.data();
     std::sort(pg->by_path.begin(), pg->by_path.end(), [=](uint64_t x, uint64_t y) {
@@ -1198,13 +1180,8 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
         pl.cv.notify_all();
         for (size_t j = 0; j < o->prg.size(); ++j) pg_add_node(pg, o->prg[j], o->read[j], o->size[j], o->fwd[j] != 0);
         if (!o->hits.empty()) {
-            if (!pg->hits.reserve_more(o->hits.size())) {
-                pl.fail(PMAP_ELIMIT, "out of host memory for the hits of the reads");
-                delete o;
-                break;
-            }
-            memcpy(pg->hits.p + pg->hits.n, o->hits.data(), o->hits.size() * sizeof(PgHit));
-            pg->hits.n += o->hits.size();
+            pg->n_hits += o->hits.size();
+            pg->hit_seg.push_back(std::move(o->hits));
         }
         delete o;
         ++next;
@@ -1217,6 +1194,7 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     pl.cv.notify_all();
     for (auto &t : threads) t.join();
     pg->by_path_valid = false;
+    pg->flat_valid = false;
     if (getenv("PMAP_TRACE_PIPELINE"))
         fprintf(stderr, "[pmap] read-file pipeline: %.3f s, %s, %zu mapping contexts; waited: sequencer for pieces %.3f s, "
                         "mappers for batches %.3f s (all of them together), retiring thread for mapped batches %.3f s\n",
@@ -1248,7 +1226,7 @@ extern "C" int pmap_pangraph_info(const pmap_pangraph_t *pg, pmap_pangraph_info_
     info->n_reads = (uint32_t) pg->reads.size();
     info->n_read_nodes = 0;
     for (auto &r : pg->reads) info->n_read_nodes += r.second.nodes.size();
-    info->n_hits = pg->hits.size();
+    info->n_hits = pg->n_hits;
     info->n_add_node_calls = pg->call_prg.size();
     return PMAP_OK;
 }
@@ -1288,8 +1266,8 @@ extern "C" int pmap_pangraph_hits(const pmap_pangraph_t *pgc, uint32_t *read_id,
     if (!pgc) return pmap_fail(PMAP_EINVAL, "null argument");
     pmap_pangraph *pg = const_cast<pmap_pangraph *>(pgc);
     pg_sort_hits(pg);
-    for (size_t i = 0; i < pg->hits.size(); ++i) {
-        const PgHit &h = pg->hits[pg->by_path[i]];
+    for (size_t i = 0; i < pg->n_hits; ++i) {
+        const PgHit &h = pg->flat[pg->by_path[i]];
         const uint32_t call = pg->hit_call[pg->by_path[i]];
         if (read_id) read_id[i] = pg->call_read[call];
         if (prg_id) prg_id[i] = pg->call_prg[call];
@@ -1323,12 +1301,15 @@ extern "C" int pmap_pangraph_call_hits(const pmap_pangraph_t *pg, uint64_t *hit_
             o += pg->call_size[j];
         }
         hit_off[n] = o;
-        if (o != pg->hits.size()) return pmap_fail(PMAP_EINVAL, "hit lists and add_node calls out of step");
+        if (o != pg->n_hits) return pmap_fail(PMAP_EINVAL, "hit lists and add_node calls out of step");
     }
-    for (size_t i = 0; i < pg->hits.size(); ++i) {
-        if (pos) pos[i] = pg->hits[i].pos;
-        if (rec) rec[i] = pg->hits[i].rec;
-    }
+    size_t i = 0;
+    for (const auto &seg : pg->hit_seg)
+        for (const PgHit &h : seg) {
+            if (pos) pos[i] = h.pos;
+            if (rec) rec[i] = h.rec;
+            ++i;
+        }
     return PMAP_OK;
 }
 
