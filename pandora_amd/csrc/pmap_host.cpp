@@ -1060,7 +1060,9 @@ unsigned parse_threads() {
         const int v = atoi(e);
         if (v > 0) hw = std::min<unsigned>(hw, (unsigned) v);
     }
-    return std::max(1u, std::min(hw, 16u) * 3 / 4);
+    // half of the cores (at most 8): the mapper threads, the sequencer and the retiring thread need the rest
+    // (16 cores, three mapping contexts: 8 parser threads 17-19 Gbases/s of FASTQ, 12 or 16 threads 15-16)
+    return std::max(1u, std::min(hw, 16u) / 2);
 }
 
 bool looks_gzipped(const char *path) {
