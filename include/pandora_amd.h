@@ -193,6 +193,13 @@ typedef struct {
  * they would after a very long one, so that the batch takes the fallback (one workgroup per kernel) it takes
  * then.  Results are the same. */
 #define PMAP_FLAG_TEST_CHAIN_GIVES_UP 16u
+/* By default one kernel sorts a read's hits, cuts the clusters and applies the size threshold while the hits are
+ * in its registers.  With PMAP_FLAG_TAIL_STAGED the sort and the two cluster kernels run one after the other,
+ * each over all hits (the flags above choose among their variants); indexes of more than 2^20 PRGs always take
+ * them.  Results are the same.  PMAP_FLAG_TEST_TAIL_NARROW: the fused kernel sorts the reads of a chunk two at a
+ * time, as it would many short reads on an index of very many PRGs. */
+#define PMAP_FLAG_TAIL_STAGED 128u
+#define PMAP_FLAG_TEST_TAIL_NARROW 256u
 
 /* 0.5 / exp(e_rate * k) as src/utils.cpp:394 evaluates it (float). */
 float pmap_fraction(float e_rate, uint32_t k);

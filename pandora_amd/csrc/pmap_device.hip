@@ -65,12 +65,19 @@ struct DevCtx {
     int device = 0;
     hipStream_t sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, tail = nullptr, tail2 = nullptr, upload = nullptr;
     unsigned sketch_turn = 0, tail_turn = 0;
-    // pmap_map_noalloc: this device's copy of the scratch array, a result object whose buffers are views
-    // of it and of the caller's outputs, pinned staging of the per-prg thresholds
-    unsigned char *scratch = nullptr;
-    pmap_result *na_view = nullptr;
-    uint32_t *thr_stage = nullptr;
 };
+// pmap_map_noalloc, per GPU (all contexts of a GPU share it): the address of this device's copy of the scratch
+// array, a result object whose buffers are views of it and of the caller's outputs, pinned staging of the
+// per-prg thresholds, and what the threshold table in the array was last computed from.  `busy` is held for the
+// length of a call: the array cannot serve two calls at once, whichever contexts they come from.
+struct NoAlloc {
+    std::mutex setup_mu;
+    unsigned char *scratch = nullptr;
+    pmap_result *view = nullptr;
+    uint32_t *thr_stage = nullptr;
+    std::atomic<bool> busy{false};
+};
+static NoAlloc g_noalloc[pmap_index::MAX_DEVICES];
 static std::mutex g_ctx_mu;                       // guards the two lists below
 static std::vector<DevCtx *> g_all_ctx;           // every context ever made (they live until the process ends)
 static std::vector<DevCtx *> g_pool;              // pmap_init_devices: the contexts of pmap_pangraph_from_read_file
@@ -109,16 +116,22 @@ static const size_t NA_OFF_TILECNT = NA_OFF_GROUP + (64u << 10);                
 static const size_t NA_OFF_HBOUNDS = NA_OFF_TILECNT + 16 * (NA_MAX_TILES + 16);            // 12 (of 16) B per read
 static const size_t NA_OFF_THR = NA_OFF_HBOUNDS + 16 * (NA_MAX_READS + 32);                // 4 B per prg
 static const size_t NA_OFF_CSTART = NA_OFF_THR + 4 * (NA_MAX_PRG + 64);                    // 4 B per cluster
-static const size_t NA_OFF_HITS = NA_OFF_CSTART + 4 * (NA_MAX_CLUSTERS + 64);              // 5 x 4 B per hit
+static const size_t NA_OFF_CHUNK = NA_OFF_CSTART + 4 * (NA_MAX_CLUSTERS + 64);             // 16 B per chunk of 128 hits
+static const size_t NA_OFF_HITS = NA_OFF_CHUNK + 16 * (NA_MAX_HITS / 128 + 16);            // 5 x 4 B per hit
 static const size_t NA_OFF_ENTS = NA_OFF_HITS + 5 * 4 * NA_MAX_HITS;                       // 32 B per tile slot
 static const size_t NA_SCRATCH_BYTES = NA_OFF_ENTS + 32 * NA_MAX_SLOTS;
+// The tile entries are dead once the hits have been emitted: the words of the long-segment sort (8 B per hit)
+// and the row slots of the fused tail kernels (32 B each) take their place.
+static const size_t NA_OFF_ROWS_TMP = NA_OFF_ENTS + 8 * NA_MAX_HITS;
+static const size_t NA_ROWS_TMP = (NA_SCRATCH_BYTES - NA_OFF_ROWS_TMP) / 32;
 static_assert(NA_SCRATCH_BYTES <= (64u << 20), "the scratch array is documented as 64 MiB");
 static_assert(NA_OFF_GROUP % 256 == 0 && NA_OFF_TILECNT % 256 == 0 && NA_OFF_HBOUNDS % 256 == 0 &&
-              NA_OFF_THR % 256 == 0 && NA_OFF_CSTART % 256 == 0 && NA_OFF_HITS % 256 == 0 && NA_OFF_ENTS % 256 == 0,
+              NA_OFF_THR % 256 == 0 && NA_OFF_CSTART % 256 == 0 && NA_OFF_CHUNK % 256 == 0 && NA_OFF_HITS % 256 == 0 &&
+                  NA_OFF_ENTS % 256 == 0 && NA_OFF_ROWS_TMP % 256 == 0,
               "every part of the scratch array starts on a 256-byte boundary");
 static __device__ __align__(256) unsigned char pmap_scratch[64u << 20];
 
-static int noalloc_setup(DevCtx *ctx);
+static int noalloc_setup(int device);
 
 // makes `ctx` the calling thread's context (and its GPU the thread's current device)
 static int bind(DevCtx *ctx) {
@@ -141,7 +154,7 @@ static int new_context(int device, DevCtx **out) {
     if (g_tail_streams > 1) HIP_TRY(hipStreamCreateWithFlags(&ctx->tail2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
     t_ctx = ctx;
-    if (int rc = noalloc_setup(ctx)) return rc;
+    if (int rc = noalloc_setup(device)) return rc;
     std::lock_guard<std::mutex> l(g_ctx_mu);
     g_all_ctx.push_back(ctx);
     *out = ctx;
@@ -311,7 +324,7 @@ struct Counters {
                                   // out, the overflow kernel has work; 2 each: done by it)
     uint32_t n_wave;              // reads on the list of the wavefront sort
     uint32_t has_wave;            // some read has a hit count the wavefront sort is for
-    uint32_t pad[1];
+    uint32_t n_long_list;         // reads on the list of tail_long_kernel
 };
 static_assert(sizeof(Counters) == 64, "Counters is the head of the state block");
 
@@ -361,9 +374,9 @@ struct pmap_reads {
     }
 };
 
-enum { KT_SKETCH = 0, KT_PROBE, KT_SCATTER, KT_SORT, KT_CLUSTER_CUT, KT_CLUSTER_KEEP, KT_COUNT };
+enum { KT_SKETCH = 0, KT_PROBE, KT_SCATTER, KT_SORT, KT_CLUSTER_CUT, KT_CLUSTER_KEEP, KT_TAIL, KT_ROWS, KT_COUNT };
 static const char *kernel_names[PMAP_N_KERNELS] = {
-    "sketch", "probe", "scatter", "sort_rank", "cluster_cut", "cluster_keep", "", "", "", "", "", "", "", "", "", ""};
+    "sketch", "probe", "scatter", "sort_rank", "cluster_cut", "cluster_keep", "tail", "rows", "", "", "", "", "", "", "", ""};
 
 struct pmap_result {
     DevCtx *ctx = nullptr;
@@ -390,7 +403,10 @@ struct pmap_result {
     DevBuf long_words;   // sort of reads with very many hits: the hit array's blocks, each sorted (8 bytes per hit)
     // clusters
     DevBuf cstart, k_rows;
+    DevBuf chunk_cnt;   // fused tail: uint4 per chunk of TAIL_C hits {clusters, kept clusters, first row slot, 0}
+    DevBuf rows_tmp;    // fused tail: rows of the kept clusters in the slots their chunks chose
     DevBuf thr;
+    uint32_t thr_minval = 0;          // smallest threshold of any prg
     std::vector<uint32_t> thr_host;
     uint64_t thr_serial = 0;          // pmap_index::serial the table was built from (0 = none yet)
     float thr_fraction = 0;
@@ -409,6 +425,7 @@ struct pmap_result {
     uint32_t p_last = 0;
     bool long_enabled = false;        // launch the long-segment sort kernels
     bool long_launched = false;       // ... and the last run did
+    bool staged_tail = false;         // the last run took the separate sort and cluster kernels
     bool wave_enabled = true;         // launch the wavefront sort kernels (off after a batch without a read for them)
     bool dense_enabled = false;       // launch the sketch kernel for tiles with more minimizers than the usual one's list holds
     bool dense_launched = false;
@@ -417,7 +434,7 @@ struct pmap_result {
     uint32_t kt_recorded = 0;
     std::vector<DevBuf *> all() {
         return {&state, &group_sum, &tile_cnt, &bsum, &scratch_total, &mkmer, &ents, &h_read, &h_key, &h_pos, &h_rank, &h_rec,
-                &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &long_words, &cstart, &k_rows, &thr};
+                &hbounds, &s_read, &s_key, &s_pos, &s_rank, &s_rec, &long_words, &cstart, &k_rows, &chunk_cnt, &rows_tmp, &thr};
     }
 };
 
@@ -708,11 +725,15 @@ static int run_pipeline(pmap_result *res) {
     // state block: counters + one 8-byte word per block of each chained prefix sum
     res->n_ablk = res->hit_cap / CUT_BLOCK;
     res->n_bblk = (res->cl_cap + KEEP_BLOCK - 1) / KEEP_BLOCK;        // (the kernel guards by the capacity itself)
+    const uint32_t n_chunks_cap = res->hit_cap / TAIL_C;                        // chunks of the fused tail kernels
+    const uint32_t n_cgrp = (n_chunks_cap + TAIL_GROUP - 1) / TAIL_GROUP + 1;   // their groups: two 8-byte sums each
     const size_t state_bytes =
-        (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_ablk + res->n_bblk + 2) + 15) & ~(size_t) 15;
+        (sizeof(Counters) + sizeof(unsigned long long) * ((size_t) res->n_ablk + res->n_bblk + 2 + 2 * (size_t) n_cgrp) + 15) &
+        ~(size_t) 15;
     if ((rc = res->state.ensure(state_bytes))) return rc;
     Counters *dc = res->state.as<Counters>();
     unsigned long long *gran_a = (unsigned long long *) (dc + 1), *gran_b = gran_a + res->n_ablk;
+    unsigned long long *cg_sum = gran_b + res->n_bblk + 2;
     const uint32_t n_groups = (uint32_t) (((size_t) n_tiles + GROUP_TILES - 1) / GROUP_TILES);
     if ((rc = res->group_sum.ensure(sizeof(uint4) * ((size_t) n_groups + 1)))) return rc;
     if (n_tiles == 0) {           // empty batch: nothing to launch
@@ -831,8 +852,74 @@ static int run_pipeline(pmap_result *res) {
         HIP_TRY(hipGetLastError());
     }
 
-    // ---- sort
-    if (last >= PMAP_STAGE_SORT && n_tiles) {
+    // ---- sort + cluster in one pass (tail_chunk_kernel), unless the separate kernels are asked for or the keys
+    // are too wide to share a word with a place
+    uint32_t key_bits = 1;
+    while (key_bits < 32 && (2ull * idx->n_prg) > (1ull << key_bits)) ++key_bits;
+    const bool staged = (prm->flags & PMAP_FLAG_TAIL_STAGED) || key_bits > TAIL_MAX_KEY_BITS;
+    res->staged_tail = staged;
+    if (!staged && last >= PMAP_STAGE_SORT && n_tiles) {
+        const bool cluster = last >= PMAP_STAGE_CLUSTER;
+        const uint32_t sort_long = std::max(std::min(g_sort_long, TAIL_BIG_MAX), TAIL_C);
+        // (a read has at most one minimizer per base and a minimizer at most max_cnt hits)
+        const uint64_t most_hits = (uint64_t) rd->max_len * idx->max_cnt;
+        res->long_launched = res->long_enabled && most_hits > sort_long;
+        TailArgs ta;
+        ta.dc = dc;
+        ta.hit_cap = res->hit_cap;
+        ta.n_reads = rd->n_reads + 1;
+        ta.key_bits = key_bits;
+        ta.ord_bits = (prm->flags & PMAP_FLAG_TEST_TAIL_NARROW) ? 1u : std::min(8u, 32u - 8u - key_bits);
+        ta.do_cluster = cluster ? 1u : 0u;
+        ta.max_diff = (int) prm->max_diff;
+        ta.min_thr = cluster ? res->thr_minval : 0u;
+        ta.slot_div = ta.min_thr + 1;
+        ta.rows_tmp_cap = res->hit_cap / ta.slot_div + 2;
+        ta.sort_long = sort_long;
+        if ((rc = res->chunk_cnt.ensure(sizeof(uint4) * ((size_t) n_chunks_cap + 2))) ||
+            (cluster && (rc = res->rows_tmp.ensure(32 * (size_t) ta.rows_tmp_cap))))
+            return rc;
+        ta.h_read = res->h_read.as<uint32_t>(); ta.h_key = res->h_key.as<uint32_t>(); ta.h_pos = res->h_pos.as<uint32_t>();
+        ta.h_rank = res->h_rank.as<uint32_t>(); ta.h_rec = res->h_rec.as<uint32_t>();
+        ta.hbounds = res->hbounds.as<uint32_t>();
+        ta.thr = res->thr.as<uint32_t>();
+        ta.s_read = res->s_read.as<uint32_t>(); ta.s_key = res->s_key.as<uint32_t>(); ta.s_pos = res->s_pos.as<uint32_t>();
+        ta.s_rank = res->s_rank.as<uint32_t>(); ta.s_rec = res->s_rec.as<uint32_t>();
+        ta.chunk_cnt = res->chunk_cnt.as<uint4>();
+        ta.cg_sum = cg_sum;
+        ta.rows_tmp = res->rows_tmp.as<uint32_t>();
+        ta.big_list = res->hbounds.as<uint32_t>() + 2 * ((size_t) rd->n_reads + 1);     // behind the bounds
+        ta.long_list = res->hbounds.as<uint32_t>() + 3 * ((size_t) rd->n_reads + 1);
+        kt.begin(KT_TAIL);
+        KLAUNCH_B(tail_chunk_kernel, dim3(n_chunks_cap), 64, ta);
+        if (most_hits > TAIL_WAVE_MAX && sort_long > TAIL_WAVE_MAX)
+            KLAUNCH_B(tail_big_kernel, dim3(std::min(rd->n_reads + 1, 1024u)), 64, ta);
+        // Reads with more hits than a wavefront sorts: the long-segment kernels, launched only once a batch has
+        // turned out to hold such a read (pmap_map_wait then maps the batch again with them, and they stay on
+        // until a batch comes without one)
+        if (res->long_launched) {
+            KLAUNCH(long_presort_kernel, dim3(std::min(res->hit_cap / SORT_LB, 1024u)), dc, res->hit_cap, res->h_read.as<uint32_t>(),
+                    res->h_key.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
+                    res->long_words.as<unsigned long long>(), sort_long);
+            KLAUNCH(long_rank_kernel, dim3(std::min(res->hit_cap / 256, 2048u)), dc, res->hit_cap, res->h_read.as<uint32_t>(),
+                    res->h_key.as<uint32_t>(), res->h_pos.as<uint32_t>(), res->h_rank.as<uint32_t>(),
+                    res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
+                    res->long_words.as<unsigned long long>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
+                    res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->s_rec.as<uint32_t>(), sort_long);
+            if (cluster) KLAUNCH_B(tail_long_kernel, dim3(std::min(rd->n_reads + 1, 256u)), 64, ta);
+        }
+        kt.end(KT_TAIL);
+        if (cluster) {
+            kt.begin(KT_ROWS);
+            KLAUNCH(rows_gather_kernel, dim3((n_chunks_cap + TAIL_GROUP - 1) / TAIL_GROUP), dc, res->hit_cap, res->chunk_cnt.as<uint4>(),
+                    cg_sum, res->rows_tmp.as<uint32_t>(), ta.rows_tmp_cap, res->k_rows.as<uint32_t>(), res->cl_cap);
+            kt.end(KT_ROWS);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+
+    // ---- sort (separate kernels)
+    if (staged && last >= PMAP_STAGE_SORT && n_tiles) {
         kt.begin(KT_SORT);
         // (a read has at most one minimizer per base and a minimizer at most max_cnt hits)
         res->long_launched = res->long_enabled && (uint64_t) rd->max_len * idx->max_cnt > g_sort_long;
@@ -893,8 +980,8 @@ static int run_pipeline(pmap_result *res) {
         HIP_TRY(hipGetLastError());
     }
 
-    // ---- cluster
-    if (last >= PMAP_STAGE_CLUSTER && n_tiles) {
+    // ---- cluster (separate kernels)
+    if (staged && last >= PMAP_STAGE_CLUSTER && n_tiles) {
         // the chained prefix sums wait for earlier workgroups; a batch whose wait ran out is mapped again with
         // one workgroup per kernel that walks the blocks itself (pmap_map_wait sets serial_scans)
         const uint32_t spin = (prm->flags & PMAP_FLAG_TEST_CHAIN_GIVES_UP) ? 0u : CHAIN_SPIN_LIMIT;
@@ -988,7 +1075,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     const uint32_t n_tiles = res->n_tiles;
     const size_t sb = sizeof(uint32_t) * (size_t) n_tiles * res->tile_stride;
     if ((rc = res->tile_cnt.ensure(sizeof(uint4) * ((size_t) n_tiles + 1))) || (rc = res->ents.ensure(8 * sb)) ||
-        (rc = res->hbounds.ensure(sizeof(uint32_t) * 3 * ((size_t) rd->n_reads + 1))))
+        (rc = res->hbounds.ensure(sizeof(uint32_t) * 4 * ((size_t) rd->n_reads + 1))))
         return rc;
     if (!fused && (rc = res->mkmer.ensure(2 * sb))) return rc;
 
@@ -997,9 +1084,13 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
         (res->thr_serial != idx->serial || res->thr_fraction != prm->fraction || res->thr_min != prm->min_cluster_size ||
          res->thr_exp != prm->expected_kmers)) {
         res->thr_host.assign(idx->n_prg + 1, 0);
-        for (uint32_t p = 0; p < idx->n_prg; ++p)
+        uint32_t lowest = idx->n_prg ? 0xFFFFFFFFu : 0u;
+        for (uint32_t p = 0; p < idx->n_prg; ++p) {
             res->thr_host[p] = pmap_threshold(idx->min_path_length[p], prm->expected_kmers, prm->fraction,
                                               prm->min_cluster_size);
+            lowest = std::min(lowest, res->thr_host[p]);
+        }
+        res->thr_minval = lowest;
         if ((rc = res->thr.ensure(sizeof(uint32_t) * res->thr_host.size()))) return rc;
         HIP_TRY(hipMemcpyAsync(res->thr.p, res->thr_host.data(), sizeof(uint32_t) * res->thr_host.size(),
                                hipMemcpyHostToDevice, g_tail));
@@ -1079,8 +1170,10 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
             again = true;
         }
         // at most one cluster per hit; when the hits overflowed the cluster count is only a lower bound
-        if (last >= PMAP_STAGE_CLUSTER && (hc.n_cl > res->cl_cap || (again && res->cl_cap < res->hit_cap / 8))) {
-            const uint64_t want = std::max<uint64_t>(hc.n_cl + hc.n_cl / 8, res->hit_cap / 8);
+        // (the fused tail keeps no list of all clusters: only the rows of the kept ones need room)
+        const uint64_t n_rows = res->staged_tail ? hc.n_cl : hc.n_kept;
+        if (last >= PMAP_STAGE_CLUSTER && (n_rows > res->cl_cap || (again && res->cl_cap < res->hit_cap / 8))) {
+            const uint64_t want = std::max<uint64_t>(n_rows + n_rows / 8, res->hit_cap / 8);
             if ((rc = ensure_cluster_buffers(res, round_up(std::min<uint64_t>(want, res->hit_cap), KEEP_BLOCK)))) return rc;
             again = true;
         }
@@ -1107,8 +1200,8 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         const float *km = res->kernel_ms;
         cn.ms[0] = km[KT_SKETCH];
         cn.ms[1] = km[KT_PROBE] + km[KT_SCATTER];
-        cn.ms[2] = km[KT_SORT];
-        cn.ms[3] = km[KT_CLUSTER_CUT] + km[KT_CLUSTER_KEEP];
+        cn.ms[2] = km[KT_SORT] + km[KT_TAIL];
+        cn.ms[3] = km[KT_CLUSTER_CUT] + km[KT_CLUSTER_KEEP] + km[KT_ROWS];
         int lastk = -1;
         for (int i = 0; i < KT_COUNT; ++i)
             if (recorded >> i & 1u) lastk = i;
@@ -1142,11 +1235,13 @@ static int new_result(pmap_result **out) {     // in the calling thread's contex
     return PMAP_OK;
 }
 
-// Once per context, with its device current (pmap_init / pmap_init_devices): the address of this device's
-// copy of the scratch array, and everything else pmap_map_noalloc would otherwise have to create per call.
-// Contexts on one device get the same address: they share that device's one array.
-static int noalloc_setup(DevCtx *ctx) {
-    if (ctx->scratch) return PMAP_OK;
+// Once per device, with that device current and a context of it bound (pmap_init / pmap_init_devices make the
+// first context of a GPU): the address of this device's copy of the scratch array, and everything else
+// pmap_map_noalloc would otherwise have to create per call.
+static int noalloc_setup(int device) {
+    NoAlloc &na = g_noalloc[device];
+    std::lock_guard<std::mutex> l(na.setup_mu);
+    if (na.scratch) return PMAP_OK;
     void *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(pmap_scratch));
     if (e != hipSuccess || !ptr)
@@ -1154,28 +1249,30 @@ static int noalloc_setup(DevCtx *ctx) {
     size_t bytes = 0;
     HIP_TRY(hipGetSymbolSize(&bytes, HIP_SYMBOL(pmap_scratch)));
     if (bytes < NA_SCRATCH_BYTES) return pmap_fail(PMAP_EHIP, "the scratch array is smaller than its layout");
-    HIP_TRY(hipHostMalloc((void **) &ctx->thr_stage, 4 * (NA_MAX_PRG + 64), hipHostMallocDefault));
-    int rc = new_result(&ctx->na_view);
+    HIP_TRY(hipHostMalloc((void **) &na.thr_stage, 4 * (NA_MAX_PRG + 64), hipHostMallocDefault));
+    int rc = new_result(&na.view);
     if (rc) return rc;
     unsigned char *base = (unsigned char *) ptr;
-    pmap_result *v = ctx->na_view;
+    pmap_result *v = na.view;
     v->state.view(base + NA_OFF_STATE, NA_OFF_GROUP - NA_OFF_STATE);
     v->group_sum.view(base + NA_OFF_GROUP, NA_OFF_TILECNT - NA_OFF_GROUP);
     v->tile_cnt.view(base + NA_OFF_TILECNT, NA_OFF_HBOUNDS - NA_OFF_TILECNT);
     v->hbounds.view(base + NA_OFF_HBOUNDS, NA_OFF_THR - NA_OFF_HBOUNDS);
     v->thr.view(base + NA_OFF_THR, NA_OFF_CSTART - NA_OFF_THR);
-    v->cstart.view(base + NA_OFF_CSTART, NA_OFF_HITS - NA_OFF_CSTART);
+    v->cstart.view(base + NA_OFF_CSTART, NA_OFF_CHUNK - NA_OFF_CSTART);
+    v->chunk_cnt.view(base + NA_OFF_CHUNK, NA_OFF_HITS - NA_OFF_CHUNK);
     DevBuf *unsorted[5] = {&v->h_read, &v->h_key, &v->h_pos, &v->h_rank, &v->h_rec};
     for (int i = 0; i < 5; ++i) unsorted[i]->view(base + NA_OFF_HITS + (size_t) i * 4 * NA_MAX_HITS, 4 * NA_MAX_HITS);
     v->ents.view(base + NA_OFF_ENTS, 32 * NA_MAX_SLOTS);
-    // the tile entries are dead once the hits have been emitted: the sort's block words take their place
-    static_assert(8 * NA_MAX_HITS <= 32 * NA_MAX_SLOTS, "the long-segment sort's words fit the entry area");
+    static_assert(NA_OFF_ROWS_TMP + 32 * NA_ROWS_TMP <= NA_SCRATCH_BYTES && NA_ROWS_TMP >= NA_MAX_HITS / 2,
+                  "the long-segment sort's words and the row slots fit the entry area");
     v->long_words.view(base + NA_OFF_ENTS, 8 * NA_MAX_HITS);
+    v->rows_tmp.view(base + NA_OFF_ROWS_TMP, 32 * NA_ROWS_TMP);
     // never used on this path (unfused mode, minimizer gather); empty views make any use fail instead of allocate
     v->mkmer.view(nullptr, 0);
     v->bsum.view(nullptr, 0);
     v->scratch_total.view(nullptr, 0);
-    ctx->scratch = base;
+    na.scratch = base;
     return PMAP_OK;
 }
 
@@ -1185,10 +1282,18 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     if (!t_ctx) return pmap_fail(PMAP_EINVAL, "call pmap_init first: pmap_map_noalloc sets nothing up by itself");
     DevCtx *ctx = rd->ctx;
     if (int rcb = bind(ctx)) return rcb;
-    if (!ctx->scratch || !ctx->na_view)
-        return pmap_fail(PMAP_EINVAL, "the reads' mapping context has no scratch array");
-    DevCtx &na = *ctx;
-    pmap_result *res = ctx->na_view;
+    NoAlloc &na = g_noalloc[ctx->device];
+    if (!na.scratch || !na.view)
+        return pmap_fail(PMAP_EINVAL, "the reads' GPU has no scratch array");
+    // one call at a time per GPU, whichever contexts and threads the calls come from
+    if (na.busy.exchange(true, std::memory_order_acquire))
+        return pmap_fail(PMAP_EINVAL, "the scratch array of this GPU is in use by another pmap_map_noalloc call");
+    struct Release {
+        std::atomic<bool> &b;
+        ~Release() { b.store(false, std::memory_order_release); }
+    } release{na.busy};
+    pmap_result *res = na.view;
+    res->ctx = ctx;                 // the streams of this call
     hipStream_t g_tail = ctx->tail;
     if (prm->k != idx->k) return pmap_fail(PMAP_EINVAL, "k differs from the k the index was built with");
     if (prm->w < 1 || prm->w > (uint32_t) SK_MAX_W) return pmap_fail(PMAP_EINVAL, "w must be in [1,64]");
@@ -1199,7 +1304,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     if (!out->hit_read || !out->hit_key || !out->hit_pos || !out->hit_rank || !out->hit_rec || !out->cluster_rows)
         return pmap_fail(PMAP_EINVAL, "null output buffer");
     // capacities as the kernels' grids want them: whole blocks of the cluster kernels
-    const uint32_t hit_cap = (uint32_t) std::min<uint64_t>(out->hit_cap / CUT_BLOCK * (uint64_t) CUT_BLOCK, NA_MAX_HITS);
+    uint32_t hit_cap = (uint32_t) std::min<uint64_t>(out->hit_cap / CUT_BLOCK * (uint64_t) CUT_BLOCK, NA_MAX_HITS);
     const uint32_t cl_cap = (uint32_t) std::min<uint64_t>(out->cluster_cap / 1024u * (uint64_t) 1024u, NA_MAX_CLUSTERS);   // as documented: multiples of 1024
     if (hit_cap == 0 || cl_cap == 0)
         return pmap_fail(PMAP_EINVAL, "output buffers must hold at least 8192 hits and 1024 clusters");
@@ -1221,8 +1326,6 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     res->n_tiles = (uint32_t) n_tiles;
     res->tile_stride = stride;
     res->have_minimizers = false;
-    res->hit_cap = hit_cap;
-    res->cl_cap = cl_cap;
     const size_t hb = 4 * (size_t) hit_cap;
     res->s_read.view(out->hit_read, hb);
     res->s_key.view(out->hit_key, hb);
@@ -1234,9 +1337,13 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     if (res->thr_serial != idx->serial || res->thr_fraction != prm->fraction || res->thr_min != prm->min_cluster_size ||
         res->thr_exp != prm->expected_kmers) {
         HIP_TRY(hipStreamSynchronize(g_tail));        // an earlier copy out of the staging buffer has finished
-        for (uint32_t p = 0; p < idx->n_prg; ++p)
+        uint32_t lowest = idx->n_prg ? 0xFFFFFFFFu : 0u;
+        for (uint32_t p = 0; p < idx->n_prg; ++p) {
             na.thr_stage[p] = pmap_threshold(idx->min_path_length[p], prm->expected_kmers, prm->fraction,
                                              prm->min_cluster_size);
+            lowest = std::min(lowest, na.thr_stage[p]);
+        }
+        res->thr_minval = lowest;
         na.thr_stage[idx->n_prg] = 0;
         HIP_TRY(hipMemcpyAsync(res->thr.p, na.thr_stage, 4 * ((size_t) idx->n_prg + 1), hipMemcpyHostToDevice, g_tail));
         HIP_TRY(hipStreamSynchronize(g_tail));        // the kernels that read the table may run on the other tail stream
@@ -1245,6 +1352,12 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
         res->thr_min = prm->min_cluster_size;
         res->thr_exp = prm->expected_kmers;
     }
+    // the fused tail kernels keep a row slot per (smallest threshold + 1) hits: with thresholds of zero the
+    // slots the array has room for bound the hits
+    if (hit_cap / (res->thr_minval + 1) + 2 > NA_ROWS_TMP)
+        hit_cap = (uint32_t) ((NA_ROWS_TMP - 2) * (uint64_t) (res->thr_minval + 1) / CUT_BLOCK * CUT_BLOCK);
+    res->hit_cap = hit_cap;
+    res->cl_cap = cl_cap;
     res->p_idx = idx;
     res->p_rd = rd;
     res->p_prm = *prm;
@@ -1290,7 +1403,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     if (hc.n_hits > hit_cap)
         return pmap_fail(PMAP_ELIMIT, "the batch has more hits than the output buffers (or pmap_map_noalloc's 2^20) hold; "
                                       "the counts say how many");
-    if (hc.n_cl > cl_cap)
+    if ((res->staged_tail ? hc.n_cl : hc.n_kept) > cl_cap)
         return pmap_fail(PMAP_ELIMIT, "the batch has more clusters than the output buffers (or pmap_map_noalloc's 2^20) hold; "
                                       "the counts say how many");
     return PMAP_OK;

@@ -893,4 +893,6 @@ __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__
     }
 }
 
+#include "pmap_tail.hip.h"
+
 #endif

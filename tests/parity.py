@@ -8,6 +8,7 @@ import oracle_lib as O
 from pandora_amd import api
 
 UINT32_MAX = 0xFFFFFFFF
+TAIL_STAGED, TAIL_NARROW = 128, 256      # PMAP_FLAG_TAIL_STAGED, PMAP_FLAG_TEST_TAIL_NARROW
 
 
 def gpu_index(si):
@@ -65,7 +66,7 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
         # unfused: the complete minimizer set per read (Seq::sketch), then everything downstream
         # (rank-counting sort for every read: PMAP_FLAG_SORT_NO_WAVE)
         res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, unfused=True,
-                            sketch=sketch, flags=32)
+                            sketch=sketch, flags=32 | TAIL_STAGED)
         cn = res.counts()
         assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
         gm = res.minimizers()
@@ -82,7 +83,16 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
         # the wavefront sort for every read it can take (PMAP_FLAG_TEST_SORT_WAVE_ALL) with the default split
         # between it and the rank counting
         res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, sketch=sketch,
-                            sort_wide=sketch is None, flags=64 if sketch is None else 0)
+                            sort_wide=sketch is None, flags=TAIL_STAGED | (64 if sketch is None else 0))
+        cn = res.counts()
+        assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
+        _check_hits_and_clusters(res, cn, orc)
+        res.close()
+
+        # the default tail: sort, cluster cut and size threshold in one kernel; with another sketch kernel, the
+        # reads of a chunk sorted two at a time (PMAP_FLAG_TEST_TAIL_NARROW)
+        res = api.map_reads(gidx, rd, w, k, max_diff, fraction, min_cluster_size, expected_kmers, sketch=sketch,
+                            flags=0 if sketch is None else TAIL_NARROW)
         cn = res.counts()
         assert cn["n_minimizers"] == len(orc["mini_kmer"]), sketch
         _check_hits_and_clusters(res, cn, orc)

@@ -356,14 +356,18 @@ def test_megabase_reads(gpu):
     res = api.map_reads(gidx, rd, 14, 15, 250, api.fraction(0.11, 15), profile=1)
     res = api.map_reads(gidx, rd, 14, 15, 250, api.fraction(0.11, 15), profile=1, result=res)
     print("megabase reads: %d hits, kernel ms %s" % (res.counts()["n_hits"], res.kernel_ms()))
+    assert res.kernel_ms()["tail"] < 20.0
+    res = api.map_reads(gidx, rd, 14, 15, 250, api.fraction(0.11, 15), profile=1, flags=128)     # the separate sort kernels
+    res = api.map_reads(gidx, rd, 14, 15, 250, api.fraction(0.11, 15), profile=1, result=res, flags=128)
     assert res.kernel_ms()["sort_rank"] < 20.0
 
 
 def test_wavefront_sort_comes_and_goes(gpu):
-    """Reads of 193 to 2048 hits are sorted by one wavefront each (a network in registers), shorter and longer
-    ones by the other sort kernels; a result object launches that kernel only while its batches hold such reads.
-    One result object over batches with and without them, every hit count from a few to beyond 2048 side by
-    side: same hits and clusters as the oracle each time."""
+    """The fused tail kernel packs reads of up to 128 hits, sorts reads of up to 1024 hits one per wavefront,
+    leaves those of up to 2048 to a second kernel and longer ones to the long-segment kernels, which a result
+    object launches only while its batches hold such reads.  The separate sort kernels (PMAP_FLAG_TAIL_STAGED)
+    split at 192, 2048 and 4096 hits.  One result object of each kind over batches with and without long reads,
+    every hit count from a few to beyond 4096 side by side: same hits and clusters as the oracle each time."""
     from parity import _check_hits_and_clusters, oracle_index
     rng = np.random.default_rng(77)
     loci = synth.make_loci(40, rng, family_frac=0.5, family_max=6)
@@ -376,21 +380,24 @@ def test_wavefront_sort_comes_and_goes(gpu):
                                               (1000, 23000), (300, 30000), (5000, 45000), (0, 250), (4000, 60000))]
     gidx = gpu_index(si)
     frac = api.fraction(0.11, 15)
-    res = None
+    res = res_staged = None
     seen = set()
     for reads in (small, mixed, mixed, small, small, mixed):
         bases, off = O.pack_reads(reads)
         ids = np.arange(len(reads), dtype=np.uint32)
         orc = O.oracle_map(oracle_index(si), bases, off, ids, 14, 15, 250, frac, 10, 0xFFFFFFFF, si.min_path_length)
         per_read = np.bincount(orc["hit_read"], minlength=len(reads))
-        seen.update("small" if n <= 192 else "wave" if n <= 1024 else "wave32" if n <= 2048 else "rank" if n <= 4096
-                    else "long" for n in per_read)
+        seen.update("packed" if n <= 128 else "small" if n <= 192 else "wave" if n <= 1024 else "wave32" if n <= 2048
+                    else "rank" if n <= 4096 else "long" for n in per_read)
         rd = api.Reads(bases, off)
         res = api.map_reads(gidx, rd, 14, 15, 250, frac, result=res)
         _check_hits_and_clusters(res, res.counts(), orc)
+        res_staged = api.map_reads(gidx, rd, 14, 15, 250, frac, result=res_staged, flags=128)
+        _check_hits_and_clusters(res_staged, res_staged.counts(), orc)
         rd.close()
-    assert seen == {"small", "wave", "wave32", "rank", "long"}, seen
+    assert seen == {"packed", "small", "wave", "wave32", "rank", "long"}, seen
     res.close()
+    res_staged.close()
     gidx.close()
 
 
@@ -404,7 +411,7 @@ def test_chained_scan_fallback(gpu):
     frac = api.fraction(0.11, 15)
     want = api.map_reads(gidx, rd, 14, 15, 250, frac)
     assert want.counts()["n_hits"] > 3 * 8192 and want.counts()["n_clusters_all"] > 1024     # several blocks in each chain
-    got = api.map_reads(gidx, rd, 14, 15, 250, frac, flags=16)
+    got = api.map_reads(gidx, rd, 14, 15, 250, frac, flags=16 | 128)       # (the chains belong to the separate kernels)
     assert got.counts()["ms"][5] >= 1, "the chain did not give up: the fallback did not run"
     for f in ("n_hits", "n_clusters_all", "n_clusters"):
         assert got.counts()[f] == want.counts()[f]
