@@ -63,7 +63,9 @@ static int g_tail_streams = default_tail_streams();
 struct pmap_result;
 struct DevCtx {
     int device = 0;
-    hipStream_t sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, tail = nullptr, tail2 = nullptr, upload = nullptr;
+    hipStream_t sketch[N_SKETCH_STREAMS] = {nullptr, nullptr}, tail = nullptr, more_tails[3] = {nullptr, nullptr, nullptr},
+                upload = nullptr;
+    int n_tails = 1;
     unsigned sketch_turn = 0, tail_turn = 0;
 };
 // pmap_map_noalloc, per GPU (all contexts of a GPU share it): the address of this device's copy of the scratch
@@ -116,8 +118,8 @@ static const size_t NA_OFF_TILECNT = NA_OFF_GROUP + (64u << 10);                
 static const size_t NA_OFF_HBOUNDS = NA_OFF_TILECNT + 16 * (NA_MAX_TILES + 16);            // 12 (of 16) B per read
 static const size_t NA_OFF_THR = NA_OFF_HBOUNDS + 16 * (NA_MAX_READS + 32);                // 4 B per prg
 static const size_t NA_OFF_CSTART = NA_OFF_THR + 4 * (NA_MAX_PRG + 64);                    // 4 B per cluster
-static const size_t NA_OFF_CHUNK = NA_OFF_CSTART + 4 * (NA_MAX_CLUSTERS + 64);             // 16 B per chunk of 128 hits
-static const size_t NA_OFF_HITS = NA_OFF_CHUNK + 16 * (NA_MAX_HITS / 128 + 16);            // 5 x 4 B per hit
+static const size_t NA_OFF_CHUNK = NA_OFF_CSTART + 4 * (NA_MAX_CLUSTERS + 64);             // 2 x 16 B per chunk of 128 hits
+static const size_t NA_OFF_HITS = NA_OFF_CHUNK + 2 * 16 * (NA_MAX_HITS / 128 + 64);        // 5 x 4 B per hit
 static const size_t NA_OFF_ENTS = NA_OFF_HITS + 5 * 4 * NA_MAX_HITS;                       // 32 B per tile slot
 static const size_t NA_SCRATCH_BYTES = NA_OFF_ENTS + 32 * NA_MAX_SLOTS;
 // The tile entries are dead once the hits have been emitted: the words of the long-segment sort (8 B per hit)
@@ -151,7 +153,8 @@ static int new_context(int device, DevCtx **out) {
     // on one GPU a low-priority sketch queue that the tail queue waits for was never scheduled
     for (auto &sk : ctx->sketch) HIP_TRY(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
-    if (g_tail_streams > 1) HIP_TRY(hipStreamCreateWithFlags(&ctx->tail2, hipStreamNonBlocking));
+    ctx->n_tails = std::max(1, std::min(g_tail_streams, 4));
+    for (int i = 1; i < ctx->n_tails; ++i) HIP_TRY(hipStreamCreateWithFlags(&ctx->more_tails[i - 1], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
     t_ctx = ctx;
     if (int rc = noalloc_setup(device)) return rc;
@@ -703,6 +706,10 @@ static uint32_t round_up(uint64_t v, uint32_t m) {
 // when res->done has happened
 // extra dynamic LDS per workgroup of the register-window sketch kernels: lowers how many of them share a
 // compute unit (6 with none; for experiments)
+// wavefronts of tail_chunk_kernel (each takes chunks in turn; PMAP_TAIL_GRID, for experiments): by default a
+// quarter of the chunks the hit buffers have room for, at least 4096 (4 per SIMD of a GPU of 256 compute units: small
+// batches gain 3 % from a grid that is resident at once) and at most 32768
+static unsigned g_tail_grid = getenv("PMAP_TAIL_GRID") ? (unsigned) std::max(64, atoi(getenv("PMAP_TAIL_GRID"))) : 0u;
 static unsigned g_sketch_pad = getenv("PMAP_SKETCH_LDS_PAD") ? (unsigned) std::max(0, atoi(getenv("PMAP_SKETCH_LDS_PAD"))) : 0;
 static int run_pipeline(pmap_result *res) {
     int rc;
@@ -716,7 +723,8 @@ static int run_pipeline(pmap_result *res) {
     if ((rc = bind(ctx))) return rc;
     const pmap_index::OnDevice &od = idx->dev[ctx->device];
     // (the kernels after the sketch kernel of successive batches do not depend on each other either)
-    hipStream_t g_tail = ctx->tail2 && (ctx->tail_turn++ & 1u) ? ctx->tail2 : ctx->tail;
+    const unsigned turn = ctx->tail_turn++ % (unsigned) ctx->n_tails;
+    hipStream_t g_tail = turn ? ctx->more_tails[turn - 1] : ctx->tail;
     hipStream_t sketch_stream = ctx->sketch[ctx->sketch_turn++ % N_SKETCH_STREAMS];
     g_cur = sketch_stream;
     const uint32_t k = prm->k, w = prm->w;
@@ -876,7 +884,7 @@ static int run_pipeline(pmap_result *res) {
         ta.slot_div = ta.min_thr + 1;
         ta.rows_tmp_cap = res->hit_cap / ta.slot_div + 2;
         ta.sort_long = sort_long;
-        if ((rc = res->chunk_cnt.ensure(sizeof(uint4) * ((size_t) n_chunks_cap + 2))) ||
+        if ((rc = res->chunk_cnt.ensure(2 * sizeof(uint4) * ((size_t) n_chunks_cap + 64))) ||
             (cluster && (rc = res->rows_tmp.ensure(32 * (size_t) ta.rows_tmp_cap))))
             return rc;
         ta.h_read = res->h_read.as<uint32_t>(); ta.h_key = res->h_key.as<uint32_t>(); ta.h_pos = res->h_pos.as<uint32_t>();
@@ -886,12 +894,14 @@ static int run_pipeline(pmap_result *res) {
         ta.s_read = res->s_read.as<uint32_t>(); ta.s_key = res->s_key.as<uint32_t>(); ta.s_pos = res->s_pos.as<uint32_t>();
         ta.s_rank = res->s_rank.as<uint32_t>(); ta.s_rec = res->s_rec.as<uint32_t>();
         ta.chunk_cnt = res->chunk_cnt.as<uint4>();
+        ta.chunk_cont = ta.chunk_cnt + n_chunks_cap + 64;
         ta.cg_sum = cg_sum;
         ta.rows_tmp = res->rows_tmp.as<uint32_t>();
         ta.big_list = res->hbounds.as<uint32_t>() + 2 * ((size_t) rd->n_reads + 1);     // behind the bounds
         ta.long_list = res->hbounds.as<uint32_t>() + 3 * ((size_t) rd->n_reads + 1);
         kt.begin(KT_TAIL);
-        KLAUNCH_B(tail_chunk_kernel, dim3(n_chunks_cap), 64, ta);
+        const uint32_t tail_grid = g_tail_grid ? g_tail_grid : std::min(std::max(n_chunks_cap / 4, 4096u), 32768u);
+        KLAUNCH_B(tail_chunk_kernel, dim3(std::min(n_chunks_cap, tail_grid)), 64, ta);
         if (most_hits > TAIL_WAVE_MAX && sort_long > TAIL_WAVE_MAX)
             KLAUNCH_B(tail_big_kernel, dim3(std::min(rd->n_reads + 1, 1024u)), 64, ta);
         // Reads with more hits than a wavefront sorts: the long-segment kernels, launched only once a batch has
@@ -906,13 +916,13 @@ static int run_pipeline(pmap_result *res) {
                     res->h_rec.as<uint32_t>(), res->hbounds.as<uint32_t>(), rd->n_reads + 1,
                     res->long_words.as<unsigned long long>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(),
                     res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->s_rec.as<uint32_t>(), sort_long);
-            if (cluster) KLAUNCH_B(tail_long_kernel, dim3(std::min(rd->n_reads + 1, 256u)), 64, ta);
+            if (cluster) KLAUNCH_B(tail_long_kernel, dim3(8 * std::min(rd->n_reads + 1, 128u)), 64, ta);
         }
         kt.end(KT_TAIL);
         if (cluster) {
             kt.begin(KT_ROWS);
-            KLAUNCH(rows_gather_kernel, dim3((n_chunks_cap + TAIL_GROUP - 1) / TAIL_GROUP), dc, res->hit_cap, res->chunk_cnt.as<uint4>(),
-                    cg_sum, res->rows_tmp.as<uint32_t>(), ta.rows_tmp_cap, res->k_rows.as<uint32_t>(), res->cl_cap);
+            KLAUNCH_B(rows_gather_kernel, dim3((n_chunks_cap + 63) / 64), 64, dc, res->hit_cap, ta.chunk_cnt, ta.chunk_cont, cg_sum,
+                      res->rows_tmp.as<uint32_t>(), ta.rows_tmp_cap, res->k_rows.as<uint32_t>(), res->cl_cap);
             kt.end(KT_ROWS);
         }
         HIP_TRY(hipGetLastError());
