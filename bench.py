@@ -38,17 +38,20 @@ except ValueError:
 
 # kernels of each phase (names of pmap_kernel_name).  The index lookup of add_read_hits runs inside the
 # sketch kernel, so "sketch+probe" is one kernel; "emit" is the construction of the hits.
+# Sort, cluster cut and size threshold are one kernel ("tail", with "rows" behind it placing the rows of the kept
+# clusters); "sort_rank", "cluster_cut" and "cluster_keep" are the separate kernels of PMAP_FLAG_TAIL_STAGED.
 PHASES = {
     "sketch+probe": ["sketch", "probe"],
     "emit": ["scatter"],
-    "sort": ["sort_rank"],
-    "cluster": ["cluster_cut", "cluster_keep"],
+    "sort+cluster": ["tail", "rows", "sort_rank", "cluster_cut", "cluster_keep"],
 }
+PMC_PHASES = ("sketch+probe", "emit", "sort", "cluster", "sort+cluster")      # keys of profiles/pmc_traffic.json
 
 ALGO_DEF = ("B read bases, M minimizers, H hits, C clusters before the size threshold.  sketch+probe: B/4 "
             "(2-bit packed reads) + 16 M (a minimizer: u64 hash, u32 position, u32 read/strand) + 16 M (one 16-byte "
-            "table slot per looked-up minimizer); emit: 36 H (16-byte record read, 20-byte hit written); sort: 40 H "
-            "(every 20-byte hit read once and written once); cluster: 24 H + 28 C")
+            "table slot per looked-up minimizer); emit: 36 H (16-byte record read, 20-byte hit written); sort+cluster: "
+            "40 H (every 20-byte hit read once and written once) + 24 H + 28 C (what a separate pass over the sorted "
+            "hits for the cluster cut would move: the fused kernel is priced as the two phases it replaces)")
 
 
 def algorithmic_bytes(cn):
@@ -56,8 +59,7 @@ def algorithmic_bytes(cn):
     return {
         "sketch+probe": B / 4 + 16 * M + 16 * M,
         "emit": 36 * H,
-        "sort": 40 * H,
-        "cluster": 24 * H + 28 * C,
+        "sort+cluster": 40 * H + 24 * H + 28 * C,
     }
 
 
@@ -254,6 +256,8 @@ def other_workload(api, synth, name, scale, depth, budget_s, n_batches=1):
         "ms_per_step": elapsed / steps * 1e3, "steps": steps, "steps_in_flight": depth, "resident_batches": n_batches,
         "bases": cn["n_bases"], "minimizers": cn["n_minimizers"], "hits": cn["n_hits"],
         "clusters_all": cn["n_clusters_all"], "clusters_kept": cn["n_clusters"],
+        # batches that were mapped again with the single-workgroup cluster kernels (PMAP_FLAG_TAIL_STAGED only)
+        "serial_reruns": int(cn["ms"][5]),
         "kernel_ms_alone": kernel_ms, "phases": phase_table(kernel_ms, algo),
         # hash-probe bandwidth: minimizers looked up per second of the kernel that does the lookups
         "lookups_per_s": (cn["n_minimizers"] / (sk * 1e-3)) if sk > 0 else 0.0,
@@ -278,7 +282,7 @@ def step_traffic(name, ms_per_step):
         rec = None
     if not rec or ms_per_step <= 0:
         return {}
-    total = sum(rec.get(p, 0.0) for p in PHASES)
+    total = sum(rec.get(p, 0.0) for p in PMC_PHASES)
     return {"step_traffic": {"bytes_per_step": total, "GBps": total / (ms_per_step * 1e-3) / 1e9,
                              "frac_of_hbm_peak": total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "source": "not measured in this run: " + str(rec.get("source"))}}
@@ -297,7 +301,7 @@ def main():
     ap.add_argument("--others", default="default",
                     help="comma-separated workloads measured after the headline one at N = 1 ('none' = skip; default: "
                          "nanopore_1k_linear, nanopore_1k_families, illumina_1k, illumina_w1, nanopore_20k, "
-                         "illumina_20k_w1, nanopore_200k while the time budget lasts)")
+                         "illumina_20k_w1, nanopore_200k, nanopore_1k_8g while the time budget lasts)")
     ap.add_argument("--others-budget", type=float, default=240.0, help="seconds the other workloads may take in all")
     ap.add_argument("--resident-batches", type=int, default=6,
                     help="batches of reads kept on the GPU and mapped in turn (the same reads in rotated order): with "
@@ -457,6 +461,7 @@ def main():
                        "parallelism": "reads sharded over %d GPU(s), index replicated" % world,
                        "steps_in_flight": depth, "resident_batches": args.resident_batches},
             "hits_per_s": total_hits * args.steps / elapsed,
+            "serial_reruns": int(cn["ms"][5]),
             "roofline": roofline,
             "phases": phases,
             "whole_step": {"algorithmic_bytes": total_algo,
@@ -475,7 +480,7 @@ def main():
         names = []
         if world == 1 and args.others != "none" and args.last_stage == 0:
             names = ["nanopore_1k_linear", "nanopore_1k_families", "illumina_1k", "illumina_w1", "nanopore_20k",
-                     "illumina_20k_w1", "nanopore_200k"] if args.others == "default" else args.others.split(",")
+                     "illumina_20k_w1", "nanopore_200k", "nanopore_1k_8g"] if args.others == "default" else args.others.split(",")
         for r in ring:
             if r is not None:
                 r.close()

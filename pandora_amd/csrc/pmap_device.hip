@@ -368,12 +368,13 @@ struct pmap_reads {
     uint32_t n_words = 0;      // packed words, each read padded to a multiple of 16 bases
     uint32_t n_tiles = 0;
     DevBuf ascii, boff, woff, rlen, rflag;
+    DevBuf wblk;     // per block of ENC_BLOCK packed words: the read that owns the block's first word
     DevBuf words;    // uint2 per packed word: {16 bases, read index}
     DevBuf rmeta;    // uint2 per read: {first position in the padded stream, length or 0 if not sketchable}
-    std::vector<uint32_t> h_woff, h_rlen;   // host staging of the per-read tables (kept: the copies are asynchronous)
+    std::vector<uint32_t> h_woff, h_rlen, h_wblk;   // host staging of the per-read tables (kept: the copies are asynchronous)
     std::vector<uint64_t> h_boff;
     uint64_t device_bytes() const {
-        return ascii.cap + boff.cap + woff.cap + rlen.cap + rflag.cap + words.cap + rmeta.cap;
+        return ascii.cap + boff.cap + woff.cap + rlen.cap + rflag.cap + wblk.cap + words.cap + rmeta.cap;
     }
 };
 
@@ -496,10 +497,11 @@ static int launch_encode(pmap_reads *rd) {
     hipStream_t g_upload = rd->ctx->upload;
     HIP_TRY(hipMemsetAsync(rd->rflag.p, 0, sizeof(uint32_t) * (rd->n_reads + 1), g_upload));
     if (rd->n_words) {
-        hipLaunchKernelGGL(encode_kernel, dim3((rd->n_words + 255) / 256), dim3(256), 0, g_upload,
+        const uint32_t n_blk = (rd->n_words + ENC_BLOCK - 1) / ENC_BLOCK;
+        hipLaunchKernelGGL(encode_kernel, dim3((n_blk + 3) / 4), dim3(256), 0, g_upload,
                            rd->ascii.as<uint32_t>(), rd->boff.as<uint64_t>(), rd->woff.as<uint32_t>(),
-                           rd->rlen.as<uint32_t>(), rd->n_reads, rd->n_words, rd->words.as<uint2>(),
-                           rd->rflag.as<uint32_t>());
+                           rd->rlen.as<uint32_t>(), rd->wblk.as<uint32_t>(), rd->n_reads, rd->n_words,
+                           rd->words.as<uint2>(), rd->rflag.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     if (rd->n_reads) {
@@ -523,6 +525,8 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
     hipStream_t g_upload = rd->ctx->upload;
     std::vector<uint32_t> &woff = rd->h_woff, &rlen = rd->h_rlen;
     std::vector<uint64_t> &boff = rd->h_boff;
+    std::vector<uint32_t> &wblk = rd->h_wblk;
+    wblk.clear();
     woff.assign(n_reads + 1, 0);
     rlen.assign(n_reads + 1, 0);
     boff.assign(n_reads + 1, 0);
@@ -537,7 +541,10 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
         rlen[r] = (uint32_t) len;
         max_len = std::max(max_len, (uint32_t) len);
         boff[r] = offsets[r] - base0;
-        words += (len + 15) / 16;
+        // the blocks of the encode kernel whose first word is one of this read's
+        const uint64_t after = words + (len + 15) / 16;
+        for (uint64_t b = (words + ENC_BLOCK - 1) / ENC_BLOCK; b * ENC_BLOCK < after; ++b) wblk.push_back(r);
+        words = after;
         if (words * 16 >= 0xFFFFF000ull)
             return pmap_fail(PMAP_ELIMIT, "batch exceeds 2^32 padded bases: split it into several batches");
     }
@@ -557,6 +564,7 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
         (rc = rd->woff.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->rlen.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
         (rc = rd->rflag.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
+        (rc = rd->wblk.ensure(sizeof(uint32_t) * (wblk.size() + 1))) ||
         (rc = rd->words.ensure(sizeof(uint2) * word_slots)) ||
         (rc = rd->rmeta.ensure(sizeof(uint2) * (n_reads + 1))))
         return rc;
@@ -568,6 +576,8 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
     if (e == hipSuccess) e = hipMemcpyAsync(rd->boff.p, boff.data(), sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
     if (e == hipSuccess) e = hipMemcpyAsync(rd->woff.p, woff.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
     if (e == hipSuccess) e = hipMemcpyAsync(rd->rlen.p, rlen.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
+    if (e == hipSuccess && !wblk.empty())
+        e = hipMemcpyAsync(rd->wblk.p, wblk.data(), sizeof(uint32_t) * wblk.size(), hipMemcpyHostToDevice, g_upload);
     if (e != hipSuccess) return pmap_fail(PMAP_EHIP, std::string("read upload: ") + hipGetErrorString(e));
     if ((rc = launch_encode(rd))) return rc;
     e = hipStreamSynchronize(g_upload);
@@ -615,7 +625,7 @@ extern "C" int pmap_reads_info(const pmap_reads_t *rd, uint32_t *n_reads, uint64
 extern "C" void pmap_reads_destroy(pmap_reads_t *rd) {
     if (!rd) return;
     if (rd->ctx) (void) bind(rd->ctx);
-    rd->ascii.release(); rd->boff.release(); rd->woff.release(); rd->rlen.release(); rd->rflag.release();
+    rd->ascii.release(); rd->boff.release(); rd->woff.release(); rd->rlen.release(); rd->rflag.release(); rd->wblk.release();
     rd->words.release(); rd->rmeta.release();
     delete rd;
 }

@@ -5,6 +5,11 @@
 // ---------------------------------------------------------------------------
 // device helpers
 
+// four consecutive 32-bit words at any 4-byte boundary
+struct __attribute__((aligned(4))) Quad4 {
+    uint32_t x, y, z, w;
+};
+
 // src/inthash.cpp:42-63
 __device__ __forceinline__ uint32_t nt4_dev(uint32_t c) {
     if (c < 4) return c;
@@ -131,44 +136,114 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restr
 }
 
 // ---------------------------------------------------------------------------
-// encode: one thread per packed word (16 bases)
-__global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict__ ascii32,
-                                                     const uint64_t *__restrict__ boff,
-                                                     const uint32_t *__restrict__ woff,
-                                                     const uint32_t *__restrict__ rlen, uint32_t n_reads,
-                                                     uint32_t n_words, uint2 *__restrict__ words,
-                                                     uint32_t *__restrict__ rflag) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_words) return;
-    // the read that owns word t: the largest r with woff[r] <= t (woff[n_reads] = n_words > t)
-    uint32_t lo = 0, hi = n_reads;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (woff[mid] <= t) lo = mid; else hi = mid;
-    }
-    const uint32_t r = lo;
-    const uint32_t j0 = (t - woff[r]) * 16, len = rlen[r];
-    const uint64_t a = boff[r] + j0;
-    const uint64_t wi = a >> 2;
-    const uint32_t sh = (uint32_t) (a & 3) * 8;
-    uint32_t x[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) x[q] = ascii32[wi + q];
+// encode (src/inthash.cpp:42-63): one wavefront per ENC_BLOCK packed words (1024 bases), one lane per word of 16
+// bases.  wblk[b] = the read that owns the block's first word (from the host, which lays the words out anyway);
+// the lanes walk on from there over the reads that start inside the block (a handful at most: wave-uniform
+// loop over the word offsets of the next reads, held one per lane).  The letters are handled four at a time
+// inside a 32-bit register: code = ((c >> 1) ^ (c >> 2)) & 3 for A, C, G, T in either case, the byte itself for
+// the raw codes 0..3; a letter is good if it is a raw code or equals the letter its code stands for (looked up
+// with one byte permute); four codes are squeezed into a byte with three shifts.
+static const uint32_t ENC_BLOCK = 256;      // four words per lane: what a wavefront waits for is asked for four at a time
+
+// bit 7 of every byte of z that is not zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t z) {
+    return (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+}
+
+// the 16 letters from letter j0 of a read of len letters that starts at byte a0 of ascii32: packed word, bad-letter flag
+struct EncIn {
+    Quad4 q4;
+    uint32_t x4, sh, j0, len;
+};
+
+__device__ __forceinline__ EncIn encode_fetch(const uint32_t *__restrict__ ascii32, uint64_t a0, uint32_t j0, uint32_t len) {
+    const uint64_t a = a0 + j0, wi = a >> 2;
+    EncIn e;
+    e.sh = (uint32_t) (a & 3);
+    e.q4 = *(const Quad4 *) (ascii32 + wi);
+    e.x4 = ascii32[wi + 4];
+    e.j0 = j0;
+    e.len = len;
+    return e;
+}
+
+__device__ __forceinline__ uint32_t encode_word(const EncIn &e, uint32_t *bad_out) {
+    const uint32_t x[5] = {e.q4.x, e.q4.y, e.q4.z, e.q4.w, e.x4};
     uint32_t word = 0, bad = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        uint32_t v = sh ? (x[q] >> sh) | (x[q + 1] << (32 - sh)) : x[q];
+        // the 4 letters j0 + 4 q ..: bytes sh .. sh + 3 of the pair x[q + 1] : x[q]
+        const uint32_t v = __builtin_amdgcn_alignbyte(x[q + 1], x[q], e.sh);
+        const uint32_t left = e.len > e.j0 + 4 * q ? e.len - (e.j0 + 4 * q) : 0u;   // letters of the read from here on
+        const uint32_t in = left >= 4 ? 0xFFFFFFFFu : (1u << (8 * left)) - 1u;      // their bytes
+        const uint32_t raw7 = ~nonzero_bytes(v & 0xFCFCFCFCu) & 0x80808080u;        // bit 7 of the bytes 0..3
+        const uint32_t raw3 = (raw7 >> 7) | (raw7 >> 6);                            // 3 in those bytes
+        uint32_t code = ((v >> 1) ^ (v >> 2)) & 0x03030303u;
+        // upper-case letter against the letter of its code ("ACGT" by code, one byte permute)
+        const uint32_t want = __builtin_amdgcn_perm(0u, 0x54474341u, code);
+        bad |= nonzero_bytes((v & 0xDFDFDFDFu) ^ want) & ~raw7 & in;
+        code = ((code & ~raw3) | (v & raw3)) & in;
+        // first letter on top: byte 0 -> bits 7:6, byte 1 -> 5:4, byte 2 -> 3:2, byte 3 -> 1:0
+        const uint32_t byte = ((code << 6) | (code >> 4) | (code >> 14) | (code >> 24)) & 0xFFu;
+        word |= byte << (24 - 8 * q);
+    }
+    *bad_out = bad;
+    return word;
+}
+
+__global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict__ ascii32,
+                                                     const uint64_t *__restrict__ boff,
+                                                     const uint32_t *__restrict__ woff,
+                                                     const uint32_t *__restrict__ rlen,
+                                                     const uint32_t *__restrict__ wblk, uint32_t n_reads,
+                                                     uint32_t n_words, uint2 *__restrict__ words,
+                                                     uint32_t *__restrict__ rflag) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t blk = blockIdx.x * 4 + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint32_t t0 = blk * ENC_BLOCK;
+    if (t0 >= n_words) return;
+    constexpr int NW = ENC_BLOCK / 64;          // words per lane: t0 + lane, t0 + 64 + lane, ...
+    const uint32_t t_last = t0 + ENC_BLOCK - 1;
+    // the read that owns a word t: the largest r with woff[r] <= t (woff[n_reads] = n_words is above every word)
+    uint32_t r[NW];
+    r[0] = (uint32_t) __builtin_amdgcn_readfirstlane((int) wblk[blk]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t i = q * 4 + b;
-            uint32_t code = nt4_dev((v >> (8 * b)) & 0xFFu);
-            if (j0 + i >= len) code = 0;
-            else if (code > 3) { bad = 1; code = 0; }
-            word |= code << (30 - 2 * i);
+    for (int u = 1; u < NW; ++u) r[u] = r[0];
+    for (uint32_t base = r[0] + 1;; base += 64) {               // wave-uniform
+        const uint32_t wv = woff[min(base + lane, n_reads)];
+        const uint32_t cnt = (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(wv <= t_last && base + lane <= n_reads));
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t wj = (uint32_t) __builtin_amdgcn_readlane((int) wv, (int) j);
+#pragma unroll
+            for (int u = 0; u < NW; ++u) r[u] += wj <= t0 + 64 * u + lane ? 1u : 0u;
+        }
+        if (cnt < 64) break;
+    }
+    uint32_t w0[NW], len[NW];
+    uint64_t b0[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        r[u] = min(r[u], n_reads - 1);                          // (only for words beyond the last one)
+        w0[u] = woff[r[u]];
+        len[u] = rlen[r[u]];
+        b0[u] = boff[r[u]];
+    }
+    EncIn e[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const uint32_t t = t0 + 64 * u + lane;
+        if (t < n_words) e[u] = encode_fetch(ascii32, b0[u], (t - w0[u]) * 16, len[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const uint32_t t = t0 + 64 * u + lane;
+        if (t < n_words) {
+            uint32_t bad;
+            const uint32_t word = encode_word(e[u], &bad);
+            words[t] = make_uint2(word, r[u]);
+            if (bad) rflag[r[u]] = 1;   // every writer stores the same value
         }
     }
-    words[t] = make_uint2(word, r);
-    if (bad) rflag[r] = 1;   // every writer stores the same value
 }
 
 // rmeta[r] = {first position of read r in the padded stream, its length, or 0 for a read with a
@@ -494,11 +569,6 @@ __global__ __launch_bounds__(256) void sort_wave_list_kernel(const uint32_t *__r
     base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
     if (take) wave_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0))] = r;
 }
-
-// four consecutive 32-bit words at any 4-byte boundary
-struct __attribute__((aligned(4))) Quad4 {
-    uint32_t x, y, z, w;
-};
 
 template <int E>
 __device__ __forceinline__ void sort_wave_segment(uint32_t lane, uint32_t r, uint32_t s, uint32_t n,

@@ -474,6 +474,9 @@ def simulate_reads(genome, n_reads, rng, mean_len=10000, sigma=0.5, e_rate=0.11,
     return bases, offsets.astype(np.uint64)
 
 
+_BIG_CACHE = {}
+
+
 def workload(name, seed=1, scale=1.0, shard=0):
     """Named synthetic workloads.  Returns (SynthIndex, bases, offsets, params dict).
 
@@ -488,7 +491,12 @@ def workload(name, seed=1, scale=1.0, shard=0):
     illumina_w1       the same with w=1 (dense minimizers; the reference's threshold rejects every cluster)
     nanopore_20k      20 000 loci with variant sites, 15 000 nanopore reads (30x of the genome), w=14 k=15
     illumina_20k_w1   20 000 loci, 400 000 reads of 150 bp, w=1 k=15
-    nanopore_200k     200 000 linear loci (27 M keys, multi-GB table), 15 000 nanopore reads, w=14 k=15
+    nanopore_200k     200 000 loci, 80 % of them with a SNP site about every 100 bases (build_snp_index: paths of one
+                      to three intervals), multi-GB table, 15 000 nanopore reads, w=14 k=15
+    nanopore_200k_linear  the same loci without sites
+    nanopore_1k_8g    the nanopore_1k index plus 7e7 keys spread evenly over the key range, one record each, on
+                      199 000 more PRGs (add_filler_records): a table of 2^28 slots (8 GB), no presence filter;
+                      the nanopore_1k reads (scale multiplies the extra keys as well as the reads)
 
     `shard` selects an independent batch of reads over the same index and genome (one per GPU rank).
     """
@@ -497,18 +505,35 @@ def workload(name, seed=1, scale=1.0, shard=0):
     w = 1 if name.endswith("_w1") else 14
     k = 15
     n_loci = 200000 if "200k" in name else 20000 if "20k" in name else 1000
-    linear = name.endswith("_linear") or "200k" in name
+    linear = name.endswith("_linear")
     if name not in ("nanopore_1k", "nanopore_1k_linear", "nanopore_1k_families", "illumina_1k", "illumina_w1",
-                    "nanopore_20k", "nanopore_20k_linear", "illumina_20k_w1", "nanopore_200k"):
+                    "nanopore_20k", "nanopore_20k_linear", "illumina_20k_w1", "nanopore_200k", "nanopore_200k_linear",
+                    "nanopore_1k_8g"):
         raise ValueError(name)
-    loci = make_loci(n_loci, rng, family_frac=0.5 if name.endswith("_families") else 0.0)
-    if linear:
+    # (a 200 000-locus index takes a minute to make: the last one is kept for the next call with the same name and seed)
+    cached = _BIG_CACHE.get((name, seed))
+    if cached is not None:
+        idx, genome = cached
+        loci = None
+    else:
+        loci = make_loci(n_loci, rng, family_frac=0.5 if name.endswith("_families") else 0.0)
+    if cached is not None:
+        pass
+    elif linear:
         idx = build_index(loci, w, k)
         genome = make_genome(loci, np.random.default_rng(seed + 1))
+    elif n_loci >= 100000:
+        idx, alt_loci, sites = build_snp_index(loci, w, k, np.random.default_rng(seed + 5))
+        genome = snp_genome(loci, alt_loci, sites, np.random.default_rng(seed + 1))
     else:
         vloci = make_variant_loci(loci, np.random.default_rng(seed + 5))
         idx = build_variant_index(vloci, w, k)
         genome = make_variant_genome(vloci, np.random.default_rng(seed + 1))
+    if cached is None and n_loci >= 100000:
+        _BIG_CACHE.clear()
+        _BIG_CACHE[(name, seed)] = (idx, genome)
+    if name.endswith("_8g"):
+        idx = add_filler_records(idx, int(7e7 * scale), 200000, np.random.default_rng(seed + 7))
     if ill:
         n_reads = int((400000 if "20k" in name else 200000) * scale)
         bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 3, shard]), fixed_len=150,
@@ -519,3 +544,163 @@ def workload(name, seed=1, scale=1.0, shard=0):
         bases, off = simulate_reads(genome, n_reads, np.random.default_rng([seed + 2, shard]))
         prm = dict(w=w, k=k, max_diff=250, e_rate=0.11, min_cluster_size=10, illumina=False)
     return idx, bases, off, prm
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Big indexes.  make_variant_loci / build_variant_index walk every locus and site in Python: fine for thousands
+# of loci, minutes for 200 000.  The two generators below work on whole arrays.
+
+def build_snp_index(loci, w, k, rng, var_frac=0.8, site_every=100, min_gap=48):
+    """Loci with biallelic SNP sites on var_frac of them, a site about every site_every bases and never closer
+    than min_gap (>= w + k - 1: a window meets at most one site), as the PRG string
+    `pre 5 A 6 C 5 post 7 G 8 T 7 ...` (test/test_cases/prg0123.fa).  Returns (SynthIndex, alt_loci): the index
+    holds the minimizer k-mers of every path (src/localPRG.cpp:333-540) - with one site per window those of
+    the haplotype with the first allele everywhere and of the one with the second allele everywhere - each
+    with its path in PRG coordinates: one interval, or three (piece, allele, piece) for a k-mer over a site;
+    records of the same (prg, path, strand) once, as Index::add_record keeps them (src/index.cpp:20-37).
+    alt_loci[i] is locus i with the second allele at every site (a genome picks per site, see snp_genome)."""
+    assert min_gap >= w + k - 1
+    n_loci = len(loci)
+    lens = np.array([len(x) for x in loci], np.int64)
+    base_off = np.concatenate([[0], np.cumsum(lens)])
+    ref = np.concatenate(loci) if n_loci else np.zeros(0, np.uint8)
+    total = int(base_off[-1])
+    # sites: candidates at random gaps of min_gap .. 2 site_every - min_gap along the concatenation, kept where
+    # they lie inside one varied locus, min_gap away from its ends
+    n_cand = int(total / site_every * 1.3) + 16
+    cand = np.cumsum(rng.integers(min_gap, 2 * site_every - min_gap + 1, n_cand))
+    cand = cand[cand < total]
+    loc = np.searchsorted(base_off, cand, side="right") - 1
+    varied = rng.random(n_loci) < var_frac
+    inside = cand - base_off[loc]
+    ok = varied[loc] & (inside >= min_gap) & (inside + 1 + min_gap < lens[loc])
+    site_pos, site_loc = cand[ok], loc[ok]                       # position in the concatenation, locus
+    alt = ref.copy()
+    alt[site_pos] = _ACGT[(_CODE[ref[site_pos]] + rng.integers(1, 4, len(site_pos))) & 3]
+    # PRG coordinates.  Site number s (0-based inside its locus) is written " (5+2s) R (6+2s) A (5+2s) ": the
+    # first allele starts after the odd marker, the second after first allele + even marker, the sequence
+    # goes on after the closing odd marker
+    first_site = np.searchsorted(site_loc, np.arange(n_loci), side="left")
+    s_no = np.arange(len(site_pos)) - first_site[site_loc]
+    def digits(v):
+        return 1 + (v >= 10).astype(np.int64) + (v >= 100) + (v >= 1000) + (v >= 10000)
+
+    odd = digits(5 + 2 * s_no) + 2
+    even = digits(6 + 2 * s_no) + 2
+    extra_before_allele0 = odd                                   # marker text before the first allele
+    extra_before_allele1 = odd + 1 + even
+    extra_total = 2 * odd + even + 1                             # everything a site adds to the string
+    # PRG coordinate of a base outside any site: its offset in the locus + what the sites of its locus before it
+    # have added (looked up per position asked for, never as arrays over all bases)
+    site_cum = np.concatenate([[0], np.cumsum(extra_total)])        # exclusive prefix over the sites
+
+    def coord_plain(x, x_locus, sites_before):
+        return x - base_off[x_locus] + site_cum[sites_before] - site_cum[first_site[x_locus]]
+
+    recs = []
+    for h, seq in ((0, ref), (1, alt)):
+        hap = [seq[base_off[i]:base_off[i + 1]] for i in range(n_loci)]
+        q, pos, key, strand = np_sketch_many(hap, w, k)
+        g = base_off[q] + pos                                    # first base of the k-mer in the concatenation
+        s = np.searchsorted(site_pos, g, side="left")            # the first site at or after it
+        over = (s < len(site_pos)) & (site_pos[np.minimum(s, len(site_pos) - 1)] < g + k)      # the k-mer covers site s
+        recs.append((h, q, pos, key, strand, g, s, over))
+    prg = np.concatenate([r[1] for r in recs]).astype(np.int64)
+    hcol = np.concatenate([np.full(len(r[1]), r[0], np.int64) for r in recs])
+    key = np.concatenate([r[3] for r in recs])
+    strand = np.concatenate([r[4] for r in recs])
+    g = np.concatenate([r[5] for r in recs])
+    s = np.concatenate([r[6] for r in recs])
+    over = np.concatenate([r[7] for r in recs])
+    # a k-mer away from any site has the same path in both haplotypes (it may be a minimizer in one of them only:
+    # its window can reach a site): one record
+    ident = (g.astype(np.uint64) << np.uint64(2)) | (strand.astype(np.uint64) << np.uint64(1)) | (over & (hcol == 1)).astype(np.uint64)
+    _, keep = np.unique(ident, return_index=True)
+    prg, hcol, key, strand, g, s, over = (x[keep] for x in (prg, hcol, key, strand, g, s, over))
+    n = len(prg)
+    sp = site_pos[np.minimum(s, max(len(site_pos) - 1, 0))] if len(site_pos) else np.zeros(n, np.int64)
+    n_iv = np.where(over, 3, 1)
+    # a k-mer whose first (last) base is the site itself has an empty first (last) piece: the reference keeps
+    # no empty interval at the ends of a path, only inside (src/localPRG.cpp:333-540 builds paths from nodes it
+    # walked), so such k-mers have two intervals
+    starts_at = over & (sp == g)
+    ends_at = over & (sp == g + k - 1)
+    n_iv = n_iv - starts_at - ends_at
+    path_off = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+    ivs = np.zeros(int(path_off[-1]), np.uint32)
+    ivl = np.zeros(int(path_off[-1]), np.uint32)
+    plain = ~over
+    ivs[path_off[:-1][plain]] = coord_plain(g[plain], prg[plain], s[plain])
+    ivl[path_off[:-1][plain]] = k
+    o = np.nonzero(over)[0]
+    if len(o):
+        so, go, spo, ho, po = s[o], g[o], sp[o], hcol[o], prg[o]
+        at = path_off[:-1][o]
+        pre_len = spo - go                                       # bases before the site
+        post_len = go + k - 1 - spo                              # bases after it
+        site_coord = coord_plain(spo, po, so)                    # where the site's text starts
+        allele_coord = site_coord + np.where(ho == 0, extra_before_allele0[so], extra_before_allele1[so])
+        post_coord = site_coord + extra_total[so] + 1
+        has_pre, has_post = pre_len > 0, post_len > 0
+        ivs[at[has_pre]] = coord_plain(go[has_pre], po[has_pre], so[has_pre])
+        ivl[at[has_pre]] = pre_len[has_pre]
+        a2 = at + has_pre
+        ivs[a2] = allele_coord
+        ivl[a2] = 1
+        a3 = a2 + 1
+        ivs[a3[has_post]] = post_coord[has_post]
+        ivl[a3[has_post]] = post_len[has_post]
+    # per locus: records in (prg, path) order get the kmer node ids 1, 2, ...; min_path_length as for a linear
+    # graph: nodes of the first haplotype + 1
+    first_iv = ivs[path_off[:-1]].astype(np.uint64)
+    order = np.lexsort((hcol, first_iv, prg))
+    per_locus = np.bincount(prg, minlength=n_loci).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(per_locus)])[:-1]
+    knode = np.zeros(n, np.uint32)
+    knode[order] = (np.arange(n, dtype=np.int64) - first[prg[order]] + 1).astype(np.uint32)
+    mpl = (np.bincount(prg[hcol == 0], minlength=n_loci) + 1).astype(np.uint32)
+    # group by key
+    order = np.argsort(key, kind="stable")
+    ukeys, firstk = np.unique(key[order], return_index=True)
+    rec_off = np.concatenate([firstk, [n]]).astype(np.uint64)
+    new_off = np.concatenate([[0], np.cumsum(n_iv[order])]).astype(np.int64)
+    gather = np.repeat(path_off[:-1][order] - new_off[:-1], n_iv[order]) + np.arange(int(new_off[-1]))
+    si = SynthIndex(k, w, ukeys, rec_off, prg[order].astype(np.uint32), knode[order], strand[order],
+                    new_off.astype(np.uint64), ivs[gather], ivl[gather], mpl)
+    alt_loci = [alt[base_off[i]:base_off[i + 1]] for i in range(n_loci)]
+    return si, alt_loci, (site_pos, base_off)
+
+
+def snp_genome(loci, alt_loci, sites, rng, spacer=(200, 2000)):
+    """As make_genome, with a random allele at every SNP site of every locus."""
+    site_pos, base_off = sites
+    ref = np.concatenate(loci)
+    alt = np.concatenate(alt_loci)
+    pick = rng.random(len(site_pos)) < 0.5
+    mixed = ref.copy()
+    mixed[site_pos[pick]] = alt[site_pos[pick]]
+    return make_genome([mixed[base_off[i]:base_off[i + 1]] for i in range(len(loci))], rng, spacer)
+
+
+def add_filler_records(si, n_fill, n_prg_total, rng, filler_mpl=100):
+    """The index `si` plus n_fill more keys spread evenly over the key range, one record each, on PRGs
+    [si.n_prg, n_prg_total): what makes a table of many gigabytes out of a small index without sketching
+    gigabases (the lookups of a read then mostly miss or hit one of these records; the loci of `si` still
+    give the reads their clusters)."""
+    k = si.k
+    draw = rng.integers(0, 1 << (2 * k), int(n_fill * 1.15) + 1024, dtype=np.uint64)
+    draw = np.unique(draw)
+    draw = draw[~np.isin(draw, si.keys, assume_unique=True)]
+    keys_new = draw[rng.permutation(len(draw))[:n_fill]]
+    n = len(keys_new)
+    n0 = len(si.rec_prg)
+    prg = rng.integers(si.n_prg, n_prg_total, n, dtype=np.uint32)
+    start = rng.integers(0, 4000, n, dtype=np.uint32)
+    return SynthIndex(
+        k, si.w, np.concatenate([si.keys, keys_new]),
+        np.concatenate([si.rec_off, si.rec_off[-1] + np.arange(1, n + 1, dtype=np.uint64)]),
+        np.concatenate([si.rec_prg, prg]), np.concatenate([si.rec_knode, np.arange(1, n + 1, dtype=np.uint32)]),
+        np.concatenate([si.rec_strand, rng.integers(0, 2, n, dtype=np.uint8)]),
+        np.concatenate([si.path_off, si.path_off[-1] + np.arange(1, n + 1, dtype=np.uint64)]),
+        np.concatenate([si.iv_start, start]), np.concatenate([si.iv_len, np.full(n, k, np.uint32)]),
+        np.concatenate([si.min_path_length, np.full(n_prg_total - si.n_prg, filler_mpl, np.uint32)]))

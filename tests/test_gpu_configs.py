@@ -81,6 +81,37 @@ def test_200k_locus_index_slices(gpu, monkeypatch, direct):
     gidx.close()
 
 
+def test_8gb_table_slice(gpu):
+    """A slot table of 2^28 slots (8 GB: beyond what one level of address translation covers): the 1 000-locus
+    index plus 7e7 keys spread evenly over the key range on 199 000 more PRGs, no presence filter, so that every
+    minimizer of a read probes the table.  A slice of the reads stage by stage against the oracle over the same
+    arrays (clusters come from the real loci, the filler keys add scattered hits), then the whole batch of
+    10 000 reads: hits of the slice's reads the same inside it."""
+    si, bases, off, prm = synth.workload("nanopore_1k_8g", seed=1)
+    gidx = gpu_index(si)
+    info = gidx.info()
+    assert info["n_keys"] > 70_000_000 and info["table_slots"] * 32 >= (8 << 30) and info["filter_bits"] == 0
+    n = 60
+    sub_off = off[:n + 1]
+    frac = api.fraction(prm["e_rate"], prm["k"])
+    cn, orc = compare_batch(si, bases[:int(sub_off[-1])], sub_off, prm["w"], prm["k"], prm["max_diff"], frac,
+                            prm["min_cluster_size"], gidx=gidx)
+    assert cn["n_hits"] > 10000 and cn["n_clusters"] > 100
+    filler = orc["hit_prg"] >= 1000
+    assert filler.sum() > 1000 and (~filler).sum() > 1000
+    rd = api.Reads(bases, off)
+    res = api.map_reads(gidx, rd, prm["w"], prm["k"], prm["max_diff"], frac, prm["min_cluster_size"])
+    h = res.hits()
+    sel = h["read"] < n
+    assert sel.sum() == cn["n_hits"]
+    np.testing.assert_array_equal(h["pos"][sel], orc["hit_pos"])
+    np.testing.assert_array_equal(h["rec"][sel], orc["hit_rec"])
+    np.testing.assert_array_equal(h["prg"][sel], orc["hit_prg"])
+    res.close()
+    rd.close()
+    gidx.close()
+
+
 @pytest.mark.parametrize("fname,w,k,max_diff,min_cluster", [
     ("oxa9_read.fasta", 14, 15, 250, 10),          # pandora map's defaults
     ("oxa9_read.fasta", 5, 15, 250, 10),           # w of test/test_cases/oxa/run_test.sh

@@ -192,6 +192,14 @@ def test_illumina_w1_full_size(gpu):
     _check_full_size("illumina_w1", ((0, 1200), (123456, 1200)), 200000, 2.5e7, 1e7)
 
 
+def test_illumina_20k_w1_full_size(gpu):
+    """BASELINE's Illumina configuration on the 20 000-locus index it names, at the bench's full size: a w = 1 index
+    of 22.6 M keys spread evenly over the key range (2 GB table, no presence filter), 400 000 reads of 150 bases,
+    every k-mer looked up, 29 M hits; the reference's thresholds (src/map_main.cpp:267-272, src/utils.cpp:413-416)
+    reject every cluster."""
+    _check_full_size("illumina_20k_w1", ((0, 1200), (234567, 1200)), 400000, 5e7, 2.5e7)
+
+
 def test_200k_locus_full_size(gpu):
     """The 200 000-locus index (2 GB table behind the key-range bitmap) with its full batch: 15 000 nanopore reads,
     7 M hits in 5 M clusters before the size threshold, reads of every hit-count class of the sort."""

@@ -21,7 +21,8 @@ import sys
 
 PHASE_OF = [("sketch_wave", "sketch+probe"), ("sketch_dpp", "sketch+probe"), ("probe_wave", "sketch+probe"), ("scan_", None),
             ("scatter_group", "emit"), ("group_reduce", "emit"), ("sort_rank", "sort"), ("sort_wave", "sort"), ("long_presort", "sort"),
-            ("long_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster")]
+            ("long_rank", "sort"), ("cluster_cut", "cluster"), ("cluster_keep", "cluster"), ("tail_", "sort+cluster"),
+            ("rows_gather", "sort+cluster")]
 
 
 def per_kernel(path):
