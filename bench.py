@@ -288,6 +288,63 @@ def step_traffic(name, ms_per_step):
                              "source": "not measured in this run: " + str(rec.get("source"))}}
 
 
+def file_mode(args):
+    """--mode file: the drop-in entry point, pmap_pangraph_from_read_file (what src/map_main.cpp:319 and
+    src/compare_main.cpp:325 would call), from a FASTQ file on disk (page cache warm) to the pangraph summary, in ONE
+    process over `--gpus` mapping contexts (pmap_init_devices): contexts 0..N-1 on GPUs 0..N-1 when the machine has
+    that many, else all of them on GPU 0 (a rehearsal of the threads and queues, not of N GPUs).  Not the headline
+    metric: the host parses, packs and uploads inside the timed region."""
+    import tempfile
+    import torch
+    import pandora_amd
+    from pandora_amd import api, synth
+    n_dev = max(torch.cuda.device_count(), 1)
+    devices = list(range(args.gpus)) if args.gpus <= n_dev else [0] * args.gpus
+    pandora_amd.init(0)
+    if args.gpus > 1 or args.file_contexts:
+        devices = devices * max(args.file_contexts, 1)
+        api.init_devices(devices)
+    si, bases, off, prm = synth.workload(args.workload, seed=1, scale=args.scale)
+    d = tempfile.mkdtemp(prefix="pmap_bench_file_")
+    path = os.path.join(d, "reads.fq")
+    one = b"".join(b"@r%d\n" % i + bases[int(off[i]):int(off[i + 1])].tobytes() + b"\n+\n" +
+                   b"I" * int(off[i + 1] - off[i]) + b"\n" for i in range(len(off) - 1))
+    with open(path, "wb") as f:
+        for _ in range(args.file_copies):
+            f.write(one)
+    size = os.path.getsize(path)
+    gidx = api.Index.create(si.k, si.keys, si.rec_off, si.rec_prg, si.rec_knode, si.rec_strand, si.path_off,
+                            si.iv_start, si.iv_len, si.min_path_length)
+    for dev in sorted(set(devices)):        # the table on every GPU before the clock starts
+        pandora_amd.init(dev)
+        gidx.upload()
+    pandora_amd.init(0)
+    n_bases = int(off[-1]) * args.file_copies
+    os.environ["PMAP_TRACE_PIPELINE"] = "1"
+    runs = []
+    for rep in range(max(args.steps, 1) if args.steps < 50 else 4):
+        t0 = time.perf_counter()
+        pg = api.pangraph_from_read_file(path, gidx, prm["w"], prm["k"], prm["max_diff"], prm["e_rate"],
+                                         prm["min_cluster_size"], genome_size=5000000, max_covg=1000000,
+                                         illumina=prm["illumina"], keep_hits=args.file_keep_hits, coverage=True)
+        dt = time.perf_counter() - t0
+        info = pg.info()
+        runs.append({"s": dt, "bases_per_s": n_bases / dt, "add_node_calls": info["n_add_node_calls"],
+                     "hits_kept": info["n_hits"]})
+        pg.close()
+    os.remove(path)
+    os.rmdir(d)
+    steady = sorted(r["bases_per_s"] for r in runs[1:] or runs)
+    return {"metric": "read bases mapped/sec (file on disk -> pangraph, pmap_pangraph_from_read_file)",
+            "value": steady[len(steady) // 2], "unit": "bases/s", "n_gpus": args.gpus, "higher_is_better": True,
+            "data": "synthetic", "dtype": "u32",
+            "config": {"workload": "%s as a FASTQ file of %d bytes (%d bases, %d reads), %d mapping contexts on devices %s"
+                                   % (args.workload, size, n_bases, (len(off) - 1) * args.file_copies, len(devices), devices),
+                       "keep_hits": args.file_keep_hits},
+            "runs": runs, "note": "first run includes making the pinned buffers; value = median of the others; the "
+                                   "per-thread wait times of every run are on stderr (PMAP_TRACE_PIPELINE)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +370,12 @@ def main():
     ap.add_argument("--last-stage", type=int, default=0,
                     help="stop the path after this stage (1 sketch, 2 hits, 3 sort, 4 clusters = all; 0 = all): for "
                          "experiments, the reported value is then not the metric")
+    ap.add_argument("--mode", default="batch", choices=["batch", "file"],
+                    help="batch (default): the metric, resident batches through pmap_map; file: the drop-in call "
+                         "pmap_pangraph_from_read_file on a FASTQ file, one process over --gpus mapping contexts")
+    ap.add_argument("--file-copies", type=int, default=40, help="--mode file: the workload's reads this many times over")
+    ap.add_argument("--file-contexts", type=int, default=0, help="--mode file: mapping contexts per GPU (0 = the library's default for one GPU, one per GPU otherwise)")
+    ap.add_argument("--file-keep-hits", action="store_true", help="--mode file: keep Read::hits")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all inside the timed steps; all kernel times come from the second pass")
     args = ap.parse_args()
@@ -326,6 +389,13 @@ def main():
         # dumps every thread's Python stack to stderr if the run is still going after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PANDORA_BENCH_WATCHDOG"]), exit=True)
+
+    if args.mode == "file":
+        if int(os.environ.get("RANK", "0")) == 0:       # one process drives every GPU
+            out = file_mode(args)
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -144,6 +144,20 @@ int pmap_reads_create(const char *bases, const uint64_t *offsets, uint32_t n_rea
 /* Replaces the batch held by `reads` with another one, reusing its device buffers. */
 int pmap_reads_update(pmap_reads_t *reads, const char *bases, const uint64_t *offsets, uint32_t n_reads,
                       uint32_t first_read_id);
+/* The same for a batch the caller has packed already: packed holds, read after read, ceil(length / 16)
+ * 32-bit words per read, 16 bases each, the first base in the top two bits (A, C, G, T = 0, 1, 2, 3 as nt4
+ * gives them, src/inthash.cpp:42-63; unused low bits zero); offsets[i+1] - offsets[i] is the length of read
+ * i (offsets as in pmap_reads_create, no bases behind them); acgt_only[i] = 0 marks a read with a letter
+ * nt4 maps to 4, which has no sketch (src/seq.cpp:49-53; its words are not looked at).  A quarter of the
+ * bytes of pmap_reads_create cross the bus: what pmap_pangraph_from_read_file does with its batches. */
+/* Packs reads for pmap_reads_create_packed (on the host): packed must have room for the sum over the reads of
+ * ceil(length / 16) words, acgt_only for n_reads bytes. */
+int pmap_pack_reads(const char *bases, const uint64_t *offsets, uint32_t n_reads, uint32_t *packed,
+                    uint8_t *acgt_only);
+int pmap_reads_create_packed(const uint32_t *packed, const uint64_t *offsets, const uint8_t *acgt_only,
+                             uint32_t n_reads, uint32_t first_read_id, pmap_reads_t **out);
+int pmap_reads_update_packed(pmap_reads_t *reads, const uint32_t *packed, const uint64_t *offsets,
+                             const uint8_t *acgt_only, uint32_t n_reads, uint32_t first_read_id);
 /* Re-runs only the device encode kernel of an uploaded batch (for measurement). */
 int pmap_reads_repack(pmap_reads_t *reads);
 int pmap_reads_info(const pmap_reads_t *reads, uint32_t *n_reads, uint64_t *n_bases, uint64_t *device_bytes);
@@ -263,14 +277,18 @@ int pmap_result_counts(const pmap_result_t *res, pmap_counts_t *out);
  * device image (one copy per GPU, held until the process ends), whose address
  * pmap_init(device) looks up once per device.  Hence the limits, reported as
  * PMAP_ELIMIT: a batch of at most 2^20 tile entry slots (about one million
- * bases after every read is padded to a multiple of 16), 2^17 reads, 2^20 hits,
- * 2^20 clusters before the size threshold, an index of at most 2^20 PRGs.
+ * bases after every read is padded to a multiple of 16), 2^17 reads, 2^20 hits
+ * (778 240 when some prg's size threshold is 0, i.e. with min_cluster_size = 0:
+ * the array then holds a row slot per hit), 2^20 clusters kept, an index of at
+ * most 2^20 PRGs.
  * Before the call: pmap_init on this device, pmap_index_upload_now(idx),
  * pmap_reads_create / pmap_reads_update for the batch.  The call blocks until
  * the outputs are complete; *counts receives the totals (also when the outputs
  * were too small: PMAP_ELIMIT, and the counts say what would have fitted).
- * Every call on one GPU uses that GPU's one array: calls that overlap on one
- * GPU race; calls on different GPUs do not. */
+ * Every call on one GPU uses that GPU's one array, whichever mapping context
+ * the reads belong to: a call that finds the array in use by another call
+ * returns PMAP_EINVAL at once (nothing of the other call is touched); calls on
+ * different GPUs do not meet. */
 int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *reads, const pmap_params_t *prm,
                      const pmap_dev_out_t *out, pmap_counts_t *counts);
 
@@ -361,8 +379,12 @@ typedef struct {
  * reads the file, applies the coverage / 10M-read stops, maps every batch on
  * the GPU, runs filter_clusters and performs the add_node sequence
  * (src/pangenome/pangraph.cpp:126-140) into a host summary.  *covg is the
- * function's return value.  A reader thread parses the file while the calling
- * thread uploads and maps one batch and post-processes the batch before it. */
+ * function's return value.  Inside the call, parser threads cut a plain file
+ * into pieces and parse them side by side (gzip input: one sequential reader),
+ * one sequencer applies the read loop's rules in file order, one mapper thread
+ * per mapping context (pmap_init_devices; by default three contexts on the
+ * calling thread's GPU) uploads and maps whole batches, and the calling thread
+ * retires the batches in file order; the call returns when the file is done. */
 int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx, const pmap_map_args_t *args,
                                  pmap_pangraph_t **out, uint32_t *covg);
 

@@ -166,6 +166,28 @@ class Reads:
         self._bases = None
 
     @staticmethod
+    def packed(bases, offsets, first_read_id=0):
+        """The same batch packed to 2 bits per base on the host (pmap_pack_reads) and uploaded as such
+        (pmap_reads_create_packed): what pangraph_from_read_file does with the batches of a file."""
+        lib = _lib.load()
+        bases = np.ascontiguousarray(np.frombuffer(bytes(bases), np.uint8) if not isinstance(bases, np.ndarray) else bases,
+                                     np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        lens = np.diff(offsets.astype(np.int64))
+        words = np.zeros(int(((lens + 15) // 16).sum()) + 1, np.uint32)
+        ok = np.zeros(n + 1, np.uint8)
+        _check(lib.pmap_pack_reads(bases.ctypes.data_as(C.c_char_p), _p(offsets, u64p), n, _p(words, u32p), _p(ok, u8p)))
+        self = Reads.__new__(Reads)
+        self._bases = None
+        self.n_reads, self.n_bases, self.first_read_id = n, int(offsets[-1] - offsets[0]), first_read_id
+        h = C.c_void_p()
+        _check(lib.pmap_reads_create_packed(_p(words, u32p), _p(offsets, u64p), _p(ok, u8p), n, first_read_id, C.byref(h)))
+        self._h = h
+        self.packed_words, self.acgt_only = words[:-1], ok[:n]
+        return self
+
+    @staticmethod
     def from_list(reads, first_read_id=0):
         bs = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in reads]
         off = np.zeros(len(bs) + 1, np.uint64)

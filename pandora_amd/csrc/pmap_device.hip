@@ -369,6 +369,8 @@ struct pmap_reads {
     uint32_t n_tiles = 0;
     DevBuf ascii, boff, woff, rlen, rflag;
     DevBuf wblk;     // per block of ENC_BLOCK packed words: the read that owns the block's first word
+    bool packed = false;            // `ascii` holds words the host packed, `rflag` the host's flags
+    std::vector<uint32_t> h_rflag;
     DevBuf words;    // uint2 per packed word: {16 bases, read index}
     DevBuf rmeta;    // uint2 per read: {first position in the padded stream, length or 0 if not sketchable}
     std::vector<uint32_t> h_woff, h_rlen, h_wblk;   // host staging of the per-read tables (kept: the copies are asynchronous)
@@ -495,13 +497,20 @@ void pmap_index_release_device(pmap_index *idx) {
 
 static int launch_encode(pmap_reads *rd) {
     hipStream_t g_upload = rd->ctx->upload;
-    HIP_TRY(hipMemsetAsync(rd->rflag.p, 0, sizeof(uint32_t) * (rd->n_reads + 1), g_upload));
+    // (a packed batch brings its bad-letter flags with it)
+    if (!rd->packed) HIP_TRY(hipMemsetAsync(rd->rflag.p, 0, sizeof(uint32_t) * (rd->n_reads + 1), g_upload));
     if (rd->n_words) {
         const uint32_t n_blk = (rd->n_words + ENC_BLOCK - 1) / ENC_BLOCK;
-        hipLaunchKernelGGL(encode_kernel, dim3((n_blk + 3) / 4), dim3(256), 0, g_upload,
-                           rd->ascii.as<uint32_t>(), rd->boff.as<uint64_t>(), rd->woff.as<uint32_t>(),
-                           rd->rlen.as<uint32_t>(), rd->wblk.as<uint32_t>(), rd->n_reads, rd->n_words,
-                           rd->words.as<uint2>(), rd->rflag.as<uint32_t>());
+        if (rd->packed)
+            hipLaunchKernelGGL(encode_kernel<true>, dim3((n_blk + 3) / 4), dim3(256), 0, g_upload,
+                               rd->ascii.as<uint32_t>(), rd->boff.as<uint64_t>(), rd->woff.as<uint32_t>(),
+                               rd->rlen.as<uint32_t>(), rd->wblk.as<uint32_t>(), rd->n_reads, rd->n_words,
+                               rd->words.as<uint2>(), rd->rflag.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(encode_kernel<false>, dim3((n_blk + 3) / 4), dim3(256), 0, g_upload,
+                               rd->ascii.as<uint32_t>(), rd->boff.as<uint64_t>(), rd->woff.as<uint32_t>(),
+                               rd->rlen.as<uint32_t>(), rd->wblk.as<uint32_t>(), rd->n_reads, rd->n_words,
+                               rd->words.as<uint2>(), rd->rflag.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     if (rd->n_reads) {
@@ -514,11 +523,14 @@ static int launch_encode(pmap_reads *rd) {
 }
 
 // fills a reads object (new or reused: its buffers only grow) with a batch and waits for the upload
+// packed != nullptr: the batch comes as 2-bit words from the host (`bases` is not looked at), acgt_only[r] = 0
+// marks a read with a letter outside ACGT
 static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets, uint32_t n_reads,
-                      uint32_t first_read_id) {
+                      uint32_t first_read_id, const uint32_t *packed = nullptr, const uint8_t *acgt_only = nullptr) {
     int rc;
-    if (!offsets || (n_reads && !bases && offsets[n_reads] != offsets[0]))
+    if (!offsets || (n_reads && !bases && !packed && offsets[n_reads] != offsets[0]))
         return pmap_fail(PMAP_EINVAL, "null argument");
+    if (packed && n_reads && !acgt_only) return pmap_fail(PMAP_EINVAL, "null argument");
     if ((uint64_t) first_read_id + n_reads > 0xFFFFFFFEull)
         return pmap_fail(PMAP_ELIMIT, "read ids exceed 32 bits (src/minihit.cpp:18-19)");
     if (int rcb = bind(rd->ctx)) return rcb;
@@ -558,7 +570,8 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
     rd->n_words = (uint32_t) words;
     rd->max_len = max_len;
     rd->n_tiles = 0;   // the tiling depends on w: pmap_map computes it
-    const size_t ascii_bytes = ((n_bases + 3) & ~3ull) + 64;
+    rd->packed = packed != nullptr;
+    const size_t ascii_bytes = packed ? 4 * (size_t) words + 64 : ((n_bases + 3) & ~3ull) + 64;
     const size_t word_slots = (size_t) words + 16;
     if ((rc = rd->ascii.ensure(ascii_bytes)) || (rc = rd->boff.ensure(sizeof(uint64_t) * (n_reads + 1))) ||
         (rc = rd->woff.ensure(sizeof(uint32_t) * (n_reads + 1))) ||
@@ -568,11 +581,19 @@ static int reads_fill(pmap_reads *rd, const char *bases, const uint64_t *offsets
         (rc = rd->words.ensure(sizeof(uint2) * word_slots)) ||
         (rc = rd->rmeta.ensure(sizeof(uint2) * (n_reads + 1))))
         return rc;
-    hipError_t e;
-    e = hipMemsetAsync((char *) rd->ascii.p + ((n_bases) & ~3ull), 0, ascii_bytes - (n_bases & ~3ull), g_upload);
+    hipError_t e = hipSuccess;
+    if (!packed) e = hipMemsetAsync((char *) rd->ascii.p + ((n_bases) & ~3ull), 0, ascii_bytes - (n_bases & ~3ull), g_upload);
     // the words after the last one are read by the sketch kernel of the last tile: keep them empty
     if (e == hipSuccess) e = hipMemsetAsync(rd->words.as<uint2>() + words, 0, sizeof(uint2) * 16, g_upload);
-    if (e == hipSuccess && n_bases) e = hipMemcpyAsync(rd->ascii.p, bases + base0, n_bases, hipMemcpyHostToDevice, g_upload);
+    if (packed) {
+        rd->h_rflag.resize(n_reads + 1);
+        for (uint32_t r = 0; r < n_reads; ++r) rd->h_rflag[r] = acgt_only[r] ? 0u : 1u;
+        rd->h_rflag[n_reads] = 0;
+        if (e == hipSuccess && words) e = hipMemcpyAsync(rd->ascii.p, packed, 4 * (size_t) words, hipMemcpyHostToDevice, g_upload);
+        if (e == hipSuccess) e = hipMemcpyAsync(rd->rflag.p, rd->h_rflag.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
+    } else if (e == hipSuccess && n_bases) {
+        e = hipMemcpyAsync(rd->ascii.p, bases + base0, n_bases, hipMemcpyHostToDevice, g_upload);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(rd->boff.p, boff.data(), sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
     if (e == hipSuccess) e = hipMemcpyAsync(rd->woff.p, woff.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
     if (e == hipSuccess) e = hipMemcpyAsync(rd->rlen.p, rlen.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice, g_upload);
@@ -604,6 +625,27 @@ extern "C" int pmap_reads_update(pmap_reads_t *rd, const char *bases, const uint
                                  uint32_t first_read_id) {
     if (!rd) return pmap_fail(PMAP_EINVAL, "null argument");
     return reads_fill(rd, bases, offsets, n_reads, first_read_id);
+}
+
+extern "C" int pmap_reads_create_packed(const uint32_t *packed, const uint64_t *offsets, const uint8_t *acgt_only,
+                                        uint32_t n_reads, uint32_t first_read_id, pmap_reads_t **out) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!out || !packed) return pmap_fail(PMAP_EINVAL, "null argument");
+    pmap_reads *rd = new pmap_reads();
+    rd->ctx = t_ctx;
+    if ((rc = reads_fill(rd, nullptr, offsets, n_reads, first_read_id, packed, acgt_only))) {
+        pmap_reads_destroy(rd);
+        return rc;
+    }
+    *out = rd;
+    return PMAP_OK;
+}
+
+extern "C" int pmap_reads_update_packed(pmap_reads_t *rd, const uint32_t *packed, const uint64_t *offsets,
+                                        const uint8_t *acgt_only, uint32_t n_reads, uint32_t first_read_id) {
+    if (!rd || !packed) return pmap_fail(PMAP_EINVAL, "null argument");
+    return reads_fill(rd, nullptr, offsets, n_reads, first_read_id, packed, acgt_only);
 }
 
 extern "C" int pmap_reads_repack(pmap_reads_t *rd) {
@@ -1010,7 +1052,7 @@ static int run_pipeline(pmap_result *res) {
         (int) prm->max_diff, gran_a, res->cl_cap, res->cstart.as<uint32_t>(), res->n_ablk, spin
 #define KEEP_ARGS                                                                                                     \
     dc, res->cl_cap, res->hit_cap, res->cstart.as<uint32_t>(), res->s_read.as<uint32_t>(), res->s_key.as<uint32_t>(), \
-        res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), gran_b,                       \
+        res->s_pos.as<uint32_t>(), res->s_rank.as<uint32_t>(), res->thr.as<uint32_t>(), idx->n_prg + 1, gran_b,      \
         res->k_rows.as<uint32_t>(), res->n_bblk, spin
         kt.begin(KT_CLUSTER_CUT);
         if (res->serial_scans) KLAUNCH_B(cluster_cut_kernel<true>, dim3(1), CUT_THREADS, CUT_ARGS);

@@ -10,6 +10,7 @@
 #include <zlib.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
+#include <tmmintrin.h>
 #endif
 
 #include <algorithm>
@@ -41,7 +42,7 @@ extern "C" int pmap_filter_clusters(uint64_t n, const uint32_t *read_id, const u
     std::iota(order, order + n, 0ull);
     // clusterComp (src/minihits.cpp:95-109): read, first position, size descending, prg, first path,
     // reverse-strand cluster before forward one
-    std::sort(order, order + n, [&](uint64_t a, uint64_t b) {
+    auto less = [&](uint64_t a, uint64_t b) {
         if (read_id[a] != read_id[b]) return read_id[a] < read_id[b];
         if (first_pos[a] != first_pos[b]) return first_pos[a] < first_pos[b];
         if (size[a] != size[b]) return size[a] > size[b];
@@ -49,7 +50,21 @@ extern "C" int pmap_filter_clusters(uint64_t n, const uint32_t *read_id, const u
         if (first_rank[a] != first_rank[b]) return first_rank[a] < first_rank[b];
         if (is_forward[a] != is_forward[b]) return is_forward[a] < is_forward[b];
         return a < b;
-    });
+    };
+    // clusters that come grouped by read in ascending order, as a mapped batch delivers them, need sorting only
+    // inside each read's handful
+    bool by_read = true;
+    for (uint64_t i = 1; i < n && by_read; ++i) by_read = read_id[i - 1] <= read_id[i];
+    if (by_read) {
+        for (uint64_t a = 0; a < n;) {
+            uint64_t b = a + 1;
+            while (b < n && read_id[b] == read_id[a]) ++b;
+            if (b - a > 1) std::sort(order + a, order + b, less);
+            a = b;
+        }
+    } else {
+        std::sort(order, order + n, less);
+    }
     for (uint64_t i = 0; i < n; ++i) alive[i] = 1;
     // filter_clusters (src/utils.cpp:256-286): compare each cluster with the closest surviving predecessor
     if (n > 0) {
@@ -239,6 +254,7 @@ struct FastaqReader {
 
 }  // namespace
 
+
 extern "C" int pmap_read_fastaq(const char *path, char **bases, uint64_t **offsets, uint32_t *n_reads,
                                 char **names, uint64_t **name_offsets) {
     FastaqReader<LineStream> fh;
@@ -277,6 +293,7 @@ extern "C" int pmap_read_fastaq(const char *path, char **bases, uint64_t **offse
 }
 
 extern "C" void pmap_free(void *p) { free(p); }
+
 
 static int read_fastaq_pieces(const char *path, uint64_t piece_bytes, char **bases, uint64_t **offsets, uint32_t *n_reads);
 
@@ -434,12 +451,29 @@ struct PinnedCache {
 };
 PinnedCache g_pinned_cache;
 
+bool all_acgt(const unsigned char *p, size_t n);
+bool pack_acgt(const unsigned char *p, size_t n, uint32_t *out);
+
+// Reads leave the host 2-bit packed (a quarter of the bytes cross the bus; at one byte per base the copies of
+// three mapper threads held the whole pipeline at what the link carries, 23 GB/s): the parser packs a read as
+// soon as it is complete, its letters still in the cache.  PMAP_HOST_PACK=0: letters travel, the GPU packs.
+bool host_pack_default() {
+    const char *e = getenv("PMAP_HOST_PACK");
+    return !e || atoi(e) != 0;
+}
+
 struct Batch {
-    char *data = nullptr;          // pinned (plain memory when `pinned` is off: parsing without a GPU)
+    char *data = nullptr;          // pinned (plain memory when `pinned` is off: parsing without a GPU, or host_pack)
     bool pinned = true;
+    bool host_pack = false;        // `words` travels instead of `data`
+    bool zero_copy = false;        // host_pack, parsed from a file in memory: reads are packed from where they lie (PackAcc),
+                                   // `data` is not used and `size` only counts letters
+    uint32_t *words = nullptr;     // pinned: ceil(length / 16) words per read
+    size_t n_words = 0, words_cap = 0;
     size_t size = 0, cap = 0;
     std::vector<uint64_t> offsets{0};
     std::vector<uint8_t> sketchable;      // per read: long enough for one window and only ACGT letters
+    std::vector<uint8_t> acgt;            // per read: only ACGT letters
     uint32_t first_id = 0;
     uint64_t seq = 0;
     pmap_params_t prm;
@@ -449,14 +483,53 @@ struct Batch {
     int exit_code = NEXT_RECORD;
     void reset() {
         size = 0;
+        n_words = 0;
         offsets.assign(1, 0);
         sketchable.clear();
+        acgt.clear();
         exit_code = NEXT_RECORD;
+    }
+    bool reserve_words(size_t want) {
+        if (want <= words_cap) return true;
+        size_t ncap = std::max(want, words_cap + words_cap / 2), got = 0;
+        char *q = g_pinned_cache.take(4 * ncap, &got);
+        if (q) ncap = got / 4;
+        else q = (char *) pmap_pinned_alloc(4 * ncap);
+        if (!q) return false;
+        if (n_words) memcpy(q, words, 4 * n_words);
+        release_words();
+        words = (uint32_t *) q;
+        words_cap = ncap;
+        return true;
+    }
+    void release_words() {
+        if (words && !g_pinned_cache.give((char *) words, 4 * words_cap)) pmap_pinned_free(words);
+        words = nullptr;
+        words_cap = 0;
+    }
+    // the read [start, start + len) of `data` is complete: packs it (host_pack) and notes whether it has a sketch
+    bool finish_read(size_t start, size_t len, uint32_t w, uint32_t k) {
+        return finish_read_at((const unsigned char *) data + start, len, w, k);
+    }
+    bool finish_read_at(const unsigned char *letters, size_t len, uint32_t w, uint32_t k) {
+        bool ok;
+        if (host_pack) {
+            const size_t nw = (len + 15) / 16;
+            if (n_words + nw > words_cap && !reserve_words(n_words + nw + (1u << 16))) return false;
+            ok = pack_acgt(letters, len, words + n_words);
+            n_words += nw;
+        } else {
+            ok = all_acgt(letters, len);
+        }
+        acgt.push_back(ok);
+        sketchable.push_back(len + 1 >= (uint64_t) w + k && ok);
+        return true;
     }
     // `live`: bytes from the start of the buffer that must survive a move (a read under construction lies
     // behind `size`)
     bool reserve(size_t want, size_t live = 0) {
         if (want <= cap) return true;
+        if (host_pack && zero_copy) return reserve_words(n_words + want / 16 + 1024);   // the letters stay in the file
         size_t ncap = std::max(want, cap + cap / 2);
         char *q = pinned ? g_pinned_cache.take(want, &ncap) : nullptr;
         if (!q) q = (char *) (pinned ? pmap_pinned_alloc(ncap) : malloc(ncap));
@@ -476,19 +549,23 @@ struct Batch {
         }
         data = nullptr;
         cap = 0;
+        release_words();
     }
-    bool append(const std::string &seq_, bool sk) {      // false: out of memory
+    bool append(const std::string &seq_, uint32_t w, uint32_t k) {      // false: out of memory
         if (size + seq_.size() > cap && !reserve(size + seq_.size() + 64)) return false;
         memcpy(data + size, seq_.data(), seq_.size());
+        const size_t start = size;
         size += seq_.size();
         offsets.push_back(size);
-        sketchable.push_back(sk);
-        return true;
+        return finish_read(start, seq_.size(), w, k);
     }
     size_t n_reads() const { return offsets.size() - 1; }
     void truncate(size_t n) {
+        if (host_pack)
+            for (size_t i = n; i < n_reads(); ++i) n_words -= (size_t) (offsets[i + 1] - offsets[i] + 15) / 16;
         offsets.resize(n + 1);
         sketchable.resize(n);
+        acgt.resize(n);
         size = offsets[n];
     }
 };
@@ -517,6 +594,64 @@ bool all_acgt(const unsigned char *p, size_t n) {
         bad |= !((u == 'A') | (u == 'C') | (u == 'G') | (u == 'T') | (c < 4));
     }
     return !bad;
+}
+
+// nt4 (src/inthash.cpp:42-63) of n letters into ceil(n / 16) words of 16 bases, the first base in the top two
+// bits, unused low bits zero; false iff some letter maps to 4 (the words are then of no use).  Letters:
+// code = ((c >> 1) ^ (c >> 2)) & 3 for A, C, G, T in either case; the bytes 0..3 stand for themselves.
+__attribute__((target("ssse3"))) bool pack_acgt_ssse3(const unsigned char *p, size_t n, uint32_t *out) {
+    const __m128i up = _mm_set1_epi8((char) 0xDF), A = _mm_set1_epi8('A'), C = _mm_set1_epi8('C'),
+                  G = _mm_set1_epi8('G'), T = _mm_set1_epi8('T'), hi = _mm_set1_epi8((char) 0xFC),
+                  zero = _mm_setzero_si128(), ones = _mm_set1_epi8((char) 0xFF), three = _mm_set1_epi8(3),
+                  m41 = _mm_set1_epi16(0x0104), m161 = _mm_set1_epi32(0x00010010);
+    __m128i acc = zero;
+    size_t i = 0, w = 0;
+    for (; i + 16 <= n; i += 16, ++w) {
+        const __m128i c = _mm_loadu_si128((const __m128i *) (p + i)), u = _mm_and_si128(c, up);
+        const __m128i raw = _mm_cmpeq_epi8(_mm_and_si128(c, hi), zero);           // c < 4
+        __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, A), _mm_cmpeq_epi8(u, C)),
+                                  _mm_or_si128(_mm_cmpeq_epi8(u, G), _mm_cmpeq_epi8(u, T)));
+        acc = _mm_or_si128(acc, _mm_andnot_si128(_mm_or_si128(ok, raw), ones));
+        __m128i code = _mm_and_si128(_mm_xor_si128(_mm_srli_epi16(c, 1), _mm_srli_epi16(c, 2)), three);
+        code = _mm_or_si128(_mm_andnot_si128(raw, code), _mm_and_si128(raw, c));
+        // pairs of letters -> 4 bits (first letter * 4 + second), pairs of those -> 8 bits, one byte per 32-bit lane
+        const __m128i nib = _mm_maddubs_epi16(code, m41);        // bytes (lo, hi) * (4, 1): lo is the earlier letter
+        const __m128i byt = _mm_madd_epi16(nib, m161);           // words (lo, hi) * (16, 1)
+        const __m128i b16 = _mm_packs_epi32(byt, byt), b8 = _mm_packus_epi16(b16, b16);
+        out[w] = __builtin_bswap32((uint32_t) _mm_cvtsi128_si32(b8));              // first four letters on top
+    }
+    bool bad = _mm_movemask_epi8(acc) != 0;
+    if (i < n) {
+        uint32_t word = 0;
+        for (size_t j = 0; i + j < n; ++j) {
+            const unsigned char c = p[i + j], u = c & 0xDFu;
+            const uint32_t code = c < 4 ? c : u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+            bad |= code > 3;
+            word |= (code & 3u) << (30 - 2 * j);
+        }
+        out[w] = word;
+    }
+    return !bad;
+}
+
+bool pack_acgt_plain(const unsigned char *p, size_t n, uint32_t *out) {
+    bool bad = false;
+    for (size_t i = 0, w = 0; i < n; i += 16, ++w) {
+        uint32_t word = 0;
+        for (size_t j = 0; j < 16 && i + j < n; ++j) {
+            const unsigned char c = p[i + j], u = c & 0xDFu;
+            const uint32_t code = c < 4 ? c : u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+            bad |= code > 3;
+            word |= (code & 3u) << (30 - 2 * j);
+        }
+        out[w] = word;
+    }
+    return !bad;
+}
+
+bool pack_acgt(const unsigned char *p, size_t n, uint32_t *out) {
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    return ssse3 ? pack_acgt_ssse3(p, n, out) : pack_acgt_plain(p, n, out);
 }
 
 // FastaqHandler's `read` member kept inside a batch's buffer: the lines of a read are copied once, to where
@@ -553,8 +688,50 @@ struct BatchAcc {
         if (oom) return false;
         b->size = start + len;
         b->offsets.push_back(b->size);
-        b->sketchable.push_back(len + 1 >= (uint64_t) w + k && all_acgt((const unsigned char *) b->data + start, len));
+        if (!b->finish_read(start, len, w, k)) { oom = true; return false; }
         returned = true;
+        return true;
+    }
+};
+
+// The same member for batches that travel packed (Batch::zero_copy): a read that is one line of the file - nearly
+// every read of a FASTQ file - is packed from where it lies in the mapped file and its letters are never copied
+// (the parser threads of a 16-core host move 4 bytes of memory traffic per base otherwise, and that, not
+// their instructions, is what bounds them); a read of several lines is put together in `own` first.
+struct PackAcc {
+    Batch *b = nullptr;
+    const char *ext = nullptr;
+    std::string own;
+    size_t len = 0;
+    bool pieced = false;        // the read's letters are in `own`
+    bool oom = false;
+    bool empty() const { return len == 0; }
+    void clear() {
+        ext = nullptr;
+        pieced = false;
+        own.clear();
+        len = 0;
+    }
+    void append(const char *p, size_t n) {
+        if (len == 0 && !pieced) {
+            ext = p;
+            len = n;
+            return;
+        }
+        if (!pieced) {
+            own.assign(ext, len);
+            pieced = true;
+        }
+        own.append(p, n);
+        len = own.size();
+    }
+    bool emit(uint32_t w, uint32_t k) {
+        b->size += len;
+        b->offsets.push_back(b->size);
+        if (!b->finish_read_at((const unsigned char *) (pieced ? own.data() : ext), len, w, k)) {
+            oom = true;
+            return false;
+        }
         return true;
     }
 };
@@ -596,6 +773,8 @@ struct Pipeline {
     const pmap_index_t *idx = nullptr;
     const pmap_map_args_t *a = nullptr;
     bool keep_hits = true, want_cov = false;
+    bool host_pack = host_pack_default();
+    bool pieces = false;            // the batches are pieces of a file in memory
     uint64_t piece_bytes = 0, batch_bases = 0;
 
     std::mutex m;
@@ -616,6 +795,12 @@ struct Pipeline {
     std::map<uint64_t, Outcome *> done;
     uint64_t covg = 0;
     double waited_parse = 0, waited_map = 0, waited_retire = 0;
+    // (PMAP_TRACE_PIPELINE) parser threads: waiting for a buffer, parsing; mapper threads: upload, map, what follows
+    double t_wait_buffer = 0, t_parse = 0, t_upload = 0, t_map = 0, t_finish = 0;
+    void add_time(double *slot, double dt) {
+        std::lock_guard<std::mutex> l(m);
+        *slot += dt;
+    }
 
     void fail(int code, const std::string &msg) {
         std::lock_guard<std::mutex> l(m);
@@ -637,6 +822,9 @@ struct Pipeline {
                 free_buffers.pop_back();
             } else {
                 b = new Batch();
+                b->host_pack = host_pack;
+                b->pinned = !host_pack;         // the letters stay on the host
+                b->zero_copy = host_pack && pieces;
                 all_buffers.push_back(b);
             }
         }
@@ -696,7 +884,7 @@ void stream_source(Pipeline *pl, FastaqReader<LineStream> *fh, pmap_params_t prm
             loop.id++;
             if (!ok) break;
         }
-        if (!b->append(seq_, sketched)) {
+        if (!b->append(seq_, pl->a->w, pl->a->k)) {
             pl->fail(PMAP_EHIP, "out of pinned host memory for a read batch");
             break;
         }
@@ -760,11 +948,12 @@ const char *find_seam(const char *from, const char *end) {
 }
 
 // runs the state machine over the piece [begin, end) (+ the seam line behind it) into the batch
-void parse_piece(Batch *b, const char *begin, const char *end, const char *file_end, uint32_t w, uint32_t k) {
+template <typename Acc>
+void parse_piece_with(Batch *b, const char *begin, const char *end, const char *file_end, uint32_t w, uint32_t k) {
     b->piece_begin = begin;
     b->piece_end = end;
     b->piece_last = end >= file_end;
-    FastaqReader<MemLines, BatchAcc> fh;
+    FastaqReader<MemLines, Acc> fh;
     fh.read.b = b;
     fh.read.clear();
     fh.in.p = begin;
@@ -793,6 +982,11 @@ void parse_piece(Batch *b, const char *begin, const char *end, const char *file_
         }
     }
     if (fh.read.oom) b->exit_code = NEXT_NO_MEMORY;
+}
+
+void parse_piece(Batch *b, const char *begin, const char *end, const char *file_end, uint32_t w, uint32_t k) {
+    if (b->zero_copy) parse_piece_with<PackAcc>(b, begin, end, file_end, w, k);
+    else parse_piece_with<BatchAcc>(b, begin, end, file_end, w, k);
 }
 
 // The pieces of a mapped file one after the other on the calling thread, with the same seam rule as the
@@ -830,8 +1024,11 @@ struct PieceSource {
         const char *file_end = file->base + file->size;
         for (;;) {
             // the buffer first, then the piece: whoever holds the lowest unparsed piece always has a buffer
+            const double tw = now_s();
             Batch *b = pl->get_buffer(pl->piece_bytes + (1u << 16));
             if (!b) return;
+            const double tp = now_s();
+            pl->add_time(&pl->t_wait_buffer, tp - tw);
             const char *begin, *end;
             {
                 std::lock_guard<std::mutex> l(m);
@@ -857,6 +1054,7 @@ struct PieceSource {
             {
                 std::lock_guard<std::mutex> l(pl->m);
                 pl->parsed[b->seq] = b;
+                pl->t_parse += now_s() - tp;
             }
             pl->cv.notify_all();
         }
@@ -992,12 +1190,19 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool
         // add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383) walks Node::reads, a multiset that
         // holds a read once per add_node call, and for each entry every hit of the read on that node: a
         // hit counts as many times as its (read, prg) has surviving clusters
-        std::map<std::pair<uint32_t, uint32_t>, uint32_t> calls;
-        for (size_t j = 0; j < nc; ++j)
-            if (alive[j]) calls[{rid[order[j]], prg[order[j]]}] += 1;
+        // (a read's clusters are consecutive in clusterComp order and few: counted pair against pair)
         std::vector<uint32_t> weight(nc, 0);
-        for (size_t j = 0; j < nc; ++j)
-            if (alive[j]) weight[order[j]] = calls[{rid[order[j]], prg[order[j]]}];
+        for (size_t a = 0; a < nc;) {
+            size_t b = a + 1;
+            while (b < nc && rid[order[b]] == rid[order[a]]) ++b;
+            for (size_t j = a; j < b; ++j) {
+                if (!alive[j]) continue;
+                uint32_t same = 0;
+                for (size_t q = a; q < b; ++q) same += alive[q] && prg[order[q]] == prg[order[j]];
+                weight[order[j]] = same;
+            }
+            a = b;
+        }
         if ((rc = pmap_coverage_add(cov, res, weight.data()))) return rc;
     }
     return PMAP_OK;
@@ -1023,14 +1228,28 @@ void mapper_thread(Pipeline *pl, void *ctx, std::vector<uint32_t> *cov_fwd, std:
             pl->ready.pop_front();
         }
         const uint32_t n = (uint32_t) b->n_reads();
-        if (!rd) rc = pmap_reads_create(b->data, b->offsets.data(), n, b->first_id, &rd);
+        const double t0 = now_s();
+        if (b->host_pack) {
+            static const uint32_t no_words = 0;
+            const uint32_t *wp = b->words ? b->words : &no_words;
+            if (!rd) rc = pmap_reads_create_packed(wp, b->offsets.data(), b->acgt.data(), n, b->first_id, &rd);
+            else rc = pmap_reads_update_packed(rd, wp, b->offsets.data(), b->acgt.data(), n, b->first_id);
+        } else if (!rd) rc = pmap_reads_create(b->data, b->offsets.data(), n, b->first_id, &rd);
         else rc = pmap_reads_update(rd, b->data, b->offsets.data(), n, b->first_id);
         const pmap_params_t prm = b->prm;
         const uint64_t seq = b->seq;
         pl->put_buffer(b);                                          // the upload has finished
         Outcome *out = new Outcome();
+        const double t1 = now_s();
         if (rc == PMAP_OK) rc = pmap_map(pl->idx, rd, &prm, &res);
+        const double t2 = now_s();
         if (rc == PMAP_OK) rc = finish_batch(pl->idx, res, out, pl->keep_hits, cov);
+        {
+            std::lock_guard<std::mutex> l(pl->m);
+            pl->t_upload += t1 - t0;
+            pl->t_map += t2 - t1;
+            pl->t_finish += now_s() - t2;
+        }
         if (rc != PMAP_OK) {
             delete out;
             break;
@@ -1052,7 +1271,7 @@ void mapper_thread(Pipeline *pl, void *ctx, std::vector<uint32_t> *cov_fwd, std:
     pmap_reads_destroy(rd);
 }
 
-unsigned parse_threads() {
+unsigned parse_threads(size_t n_contexts) {
     if (const char *e = getenv("PMAP_PARSE_THREADS")) return (unsigned) std::max(0, atoi(e));
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 4;
@@ -1060,9 +1279,11 @@ unsigned parse_threads() {
         const int v = atoi(e);
         if (v > 0) hw = std::min<unsigned>(hw, (unsigned) v);
     }
-    // half of the cores (at most 8): the mapper threads, the sequencer and the retiring thread need the rest
-    // (16 cores, three mapping contexts: 8 parser threads 17-19 Gbases/s of FASTQ, 12 or 16 threads 15-16)
-    return std::max(1u, std::min(hw, 16u) / 2);
+    // the cores the mapper threads (one per context; light since the reads travel packed and a batch's clusters
+    // are sorted read by read), the sequencer and the retiring thread leave, at most 4 per mapping context
+    const unsigned others = (unsigned) n_contexts + 2;
+    const unsigned want = hw > others + 2 ? hw - others : 2u;
+    return std::max(1u, std::min<unsigned>(want, 4u * (unsigned) std::max<size_t>(n_contexts, 1)));
 }
 
 bool looks_gzipped(const char *path) {
@@ -1075,6 +1296,20 @@ bool looks_gzipped(const char *path) {
 }
 
 }  // namespace
+
+extern "C" int pmap_pack_reads(const char *bases, const uint64_t *offsets, uint32_t n_reads, uint32_t *packed,
+                               uint8_t *acgt_only) {
+    if (!offsets || (n_reads && (!packed || !acgt_only))) return pmap_fail(PMAP_EINVAL, "null argument");
+    size_t w = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        if (offsets[r + 1] < offsets[r]) return pmap_fail(PMAP_EINVAL, "read offsets not monotone");
+        const size_t len = (size_t) (offsets[r + 1] - offsets[r]);
+        if (len && !bases) return pmap_fail(PMAP_EINVAL, "null argument");
+        acgt_only[r] = pack_acgt((const unsigned char *) bases + offsets[r], len, packed + w) ? 1 : 0;
+        w += (len + 15) / 16;
+    }
+    return PMAP_OK;
+}
 
 static int read_fastaq_pieces(const char *path, uint64_t piece_bytes, char **bases, uint64_t **offsets, uint32_t *n_reads) {
     MappedFile mapped;
@@ -1141,7 +1376,7 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     // the file must open (src/fastaq_handler.cpp:18-21) before any thread starts
     FastaqReader<LineStream> fh;
     MappedFile mapped;
-    const unsigned n_parse = parse_threads();
+    const unsigned n_parse = parse_threads(contexts.size());
     const bool parallel = n_parse > 0 && !looks_gzipped(reads_path) && mapped.open(reads_path);
     if (!parallel && !fh.in.open(reads_path))
         return pmap_fail(PMAP_EIO, std::string("Unable to open fastaq file ") + reads_path);
@@ -1153,6 +1388,7 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
 
     std::vector<std::thread> threads;
     PieceSource src{&pl, &mapped};
+    pl.pieces = parallel;
     if (parallel) {
         src.cur = mapped.base;
         const unsigned workers = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(n_parse, mapped.size / std::max<uint64_t>(pl.piece_bytes, 1) + 1));
@@ -1199,9 +1435,12 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     pg->flat_valid = false;
     if (getenv("PMAP_TRACE_PIPELINE"))
         fprintf(stderr, "[pmap] read-file pipeline: %.3f s, %s, %zu mapping contexts; waited: sequencer for pieces %.3f s, "
-                        "mappers for batches %.3f s (all of them together), retiring thread for mapped batches %.3f s\n",
+                        "mappers for batches %.3f s (all of them together), retiring thread for mapped batches %.3f s; "
+                        "parser threads together: %.3f s waiting for a buffer, %.3f s parsing; mapper threads together: "
+                        "%.3f s upload, %.3f s map, %.3f s filter + coverage\n",
                 now_s() - t_start, parallel ? "mapped file parsed in pieces" : "one parsing thread", contexts.size(),
-                pl.waited_parse, pl.waited_map, pl.waited_retire);
+                pl.waited_parse, pl.waited_map, pl.waited_retire, pl.t_wait_buffer, pl.t_parse, pl.t_upload, pl.t_map,
+                pl.t_finish);
     if (pl.rc != PMAP_OK) {
         const int code = pl.rc;
         const std::string msg = pl.error;

@@ -191,6 +191,9 @@ __device__ __forceinline__ uint32_t encode_word(const EncIn &e, uint32_t *bad_ou
     return word;
 }
 
+// PACKED: the batch came 2-bit packed from the host (pmap_reads_update_packed): ascii32 holds the packed words,
+// one per 16 bases, and the kernel only pairs every word with its read.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict__ ascii32,
                                                      const uint64_t *__restrict__ boff,
                                                      const uint32_t *__restrict__ woff,
@@ -227,6 +230,14 @@ __global__ __launch_bounds__(256) void encode_kernel(const uint32_t *__restrict_
         w0[u] = woff[r[u]];
         len[u] = rlen[r[u]];
         b0[u] = boff[r[u]];
+    }
+    if constexpr (PACKED) {
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const uint32_t t = t0 + 64 * u + lane;
+            if (t < n_words) words[t] = make_uint2(ascii32[t], r[u]);
+        }
+        return;
     }
     EncIn e[NW];
 #pragma unroll
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__
                                                                     const uint32_t *__restrict__ s_key,
                                                                     const uint32_t *__restrict__ s_pos,
                                                                     const uint32_t *__restrict__ s_rank,
-                                                                    const uint32_t *__restrict__ thr,
+                                                                    const uint32_t *__restrict__ thr, uint32_t thr_n,
                                                                     unsigned long long *__restrict__ gran,
                                                                     uint32_t *__restrict__ k_rows, uint32_t n_blocks,
                                                                     uint32_t spin_limit) {
@@ -925,8 +936,15 @@ __global__ __launch_bounds__(KEEP_THREADS) void cluster_keep_kernel(Counters *__
         if (c < n_cl) {
             s[r] = cstart[c];
             e[r] = c + 1 < n_cl ? cstart[c + 1] : n_hits;
-            key[r] = s_key[s[r]];
-            kept[r] = e[r] - s[r] > thr[key[r] >> 1];
+            // When a chained prefix sum of the kernel before gave up waiting, cluster starts were written to wrong
+            // places and some entries of cstart hold whatever the buffer held before: the batch will be mapped
+            // again, but nothing here may be used as an index unchecked.
+            if (s[r] < e[r] && e[r] <= n_hits) {
+                key[r] = s_key[s[r]];
+                kept[r] = e[r] - s[r] > thr[min(key[r] >> 1, thr_n - 1)];
+            } else {
+                s[r] = e[r] = 0;
+            }
         }
         const unsigned long long m = ballot64(kept[r]);
         rank[r] = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));

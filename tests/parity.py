@@ -98,6 +98,14 @@ def compare_batch(si, bases, offsets, w, k, max_diff, fraction, min_cluster_size
         _check_hits_and_clusters(res, cn, orc)
         res.close()
     rd.close()
+    # the same batch packed to 2 bits per base on the host (what pangraph_from_read_file sends)
+    rdp = api.Reads.packed(bases, offsets, first_read_id)
+    res = api.map_reads(gidx, rdp, w, k, max_diff, fraction, min_cluster_size, expected_kmers)
+    cn = res.counts()
+    assert cn["n_minimizers"] == len(orc["mini_kmer"])
+    _check_hits_and_clusters(res, cn, orc)
+    res.close()
+    rdp.close()
     if own:
         gidx.close()
     return cn, orc

@@ -422,3 +422,36 @@ def test_read_fastaq_in_pieces_random_files(tmp_path):
             assert [r for _, r in api.read_fastaq(p)] == want, buf
         for piece in (1, 2, 4, 9, 30, 1000):
             assert api.read_fastaq_pieces(p, piece) == want, (buf, piece)
+
+
+def test_pack_reads_is_nt4():
+    """pmap_pack_reads (what the parser threads of pangraph_from_read_file do to every read): nt4
+    (src/inthash.cpp:42-63) of every letter, 16 to a word with the first base on top; a read with a letter that
+    maps to 4 is flagged (it has no sketch, src/seq.cpp:49-53)."""
+    import ctypes as C
+    from pandora_amd import _lib
+    from pandora_amd._lib import u8p, u32p, u64p
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGTacgtNnUu\x00\x01\x02\x03-", np.uint8)
+    weight = np.array([1, 1, 1, 1, .3, .3, .3, .3, .02, .02, .02, .02, .05, .05, .05, .05, .01])
+    for trial in range(200):
+        n = int(rng.integers(0, 40))
+        lens = rng.integers(0, 90, n)
+        bases = rng.choice(alphabet, int(lens.sum()), p=weight / weight.sum()).astype(np.uint8)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        words = np.zeros(int(((lens + 15) // 16).sum()) + 1, np.uint32)
+        ok = np.zeros(n + 1, np.uint8)
+        assert lib.pmap_pack_reads(bases.ctypes.data_as(C.c_char_p), off.ctypes.data_as(u64p), n,
+                                   words.ctypes.data_as(u32p), ok.ctypes.data_as(u8p)) == 0
+        w = 0
+        for r in range(n):
+            codes = np.array([O.lib().orc_nt4(int(c)) for c in bases[int(off[r]):int(off[r + 1])]], np.uint64)
+            good = bool((codes < 4).all())
+            assert bool(ok[r]) == good
+            nw = (len(codes) + 15) // 16
+            if good:
+                for j in range(nw):
+                    want = sum(int(x) << (30 - 2 * i) for i, x in enumerate(codes[16 * j:16 * j + 16]))
+                    assert int(words[w + j]) == want
+            w += nw
