@@ -5,7 +5,7 @@ while [ "$1" != "--" ]; do settings+=("$1"); shift; done
 shift
 for wl in "$@"; do
   for st in "${settings[@]}"; do
-    tag=$(echo "$st" | tr ' =' '__')
+    tag=$(echo "$st" | tr ' =/.' '____')
     env $st timeout -k 10 200 python bench.py --steps 300 --no-cpu-baseline --others none --workload $wl ${BENCH_ARGS:-} > gpurun_out/r3/env_${wl}_$tag.json 2> gpurun_out/r3/env_${wl}_$tag.err || { echo "run $wl $st failed"; tail -5 gpurun_out/r3/env_${wl}_$tag.err; exit 1; }
     python - <<PY
 import json
