@@ -432,6 +432,7 @@ struct pmap_result {
     bool long_enabled = false;        // launch the long-segment sort kernels
     bool long_launched = false;       // ... and the last run did
     bool staged_tail = false;         // the last run took the separate sort and cluster kernels
+    bool few_hits = false;            // the last batch had so few hits per read that those kernels are the quicker ones
     bool wave_enabled = true;         // launch the wavefront sort kernels (off after a batch without a read for them)
     bool dense_enabled = false;       // launch the sketch kernel for tiles with more minimizers than the usual one's list holds
     bool dense_launched = false;
@@ -761,6 +762,12 @@ static uint32_t round_up(uint64_t v, uint32_t m) {
 // wavefronts of tail_chunk_kernel (each takes chunks in turn; PMAP_TAIL_GRID, for experiments): by default a
 // quarter of the chunks the hit buffers have room for, at least 4096 (4 per SIMD of a GPU of 256 compute units: small
 // batches gain 3 % from a grid that is resident at once) and at most 32768
+// Batches of many reads with few hits each (150-base reads under a sparse sketch: 8 hits per read) go through the
+// separate sort and cluster kernels: a chunk of the fused tail kernel then holds 15 reads, its wavefront's chain of
+// dependent loads is as long as for two reads, and the rank counting of the separate sort kernel costs next to
+// nothing (measured on 200 000 reads of 150 bases, w = 14: 245 against 190 Gbases/s).  A result object decides by
+// its previous batch.  PMAP_TAIL_AUTO: hits per read below which it does so (default 16; 0: never).
+static unsigned g_tail_auto = getenv("PMAP_TAIL_AUTO") ? (unsigned) std::max(0, atoi(getenv("PMAP_TAIL_AUTO"))) : 16u;
 static unsigned g_tail_grid = getenv("PMAP_TAIL_GRID") ? (unsigned) std::max(64, atoi(getenv("PMAP_TAIL_GRID"))) : 0u;
 static unsigned g_sketch_pad = getenv("PMAP_SKETCH_LDS_PAD") ? (unsigned) std::max(0, atoi(getenv("PMAP_SKETCH_LDS_PAD"))) : 0;
 static int run_pipeline(pmap_result *res) {
@@ -916,7 +923,8 @@ static int run_pipeline(pmap_result *res) {
     // are too wide to share a word with a place
     uint32_t key_bits = 1;
     while (key_bits < 32 && (2ull * idx->n_prg) > (1ull << key_bits)) ++key_bits;
-    const bool staged = (prm->flags & PMAP_FLAG_TAIL_STAGED) || key_bits > TAIL_MAX_KEY_BITS;
+    const bool staged = (prm->flags & PMAP_FLAG_TAIL_STAGED) || key_bits > TAIL_MAX_KEY_BITS ||
+                        (res->few_hits && !(prm->flags & PMAP_FLAG_TEST_TAIL_NARROW));
     res->staged_tail = staged;
     if (!staged && last >= PMAP_STAGE_SORT && n_tiles) {
         const bool cluster = last >= PMAP_STAGE_CLUSTER;
@@ -1245,6 +1253,7 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         if ((rc = run_pipeline(res))) return rc;
     }
     const Counters &hc = *res->hc;
+    res->few_hits = last >= PMAP_STAGE_CLUSTER && res->p_rd->n_reads >= 1024 && n_hits < (unsigned long long) g_tail_auto * res->p_rd->n_reads;
     cn.n_minimizers = n_mini;
     cn.n_hits = last >= PMAP_STAGE_HITS ? n_hits : 0;
     cn.n_clusters_all = last >= PMAP_STAGE_CLUSTER ? hc.n_cl : 0;
@@ -1255,8 +1264,9 @@ extern "C" int pmap_map_wait(pmap_result_t *res) {
         const uint32_t recorded = res->kt_recorded;
         for (int i = 0; i < KT_COUNT; ++i) {
             float ms = 0;
-            if ((recorded >> i & 1u) && hipEventElapsedTime(&ms, res->kev[2 * i], res->kev[2 * i + 1]) == hipSuccess)
-                res->kernel_ms[i] = ms;
+            // (a kernel that did not run in this call reads 0, not the time of an earlier call)
+            if (!(recorded >> i & 1u) || hipEventElapsedTime(&ms, res->kev[2 * i], res->kev[2 * i + 1]) != hipSuccess) ms = 0;
+            res->kernel_ms[i] = ms;
         }
         // stage times = sums of their kernels; ms[4] = first kernel start to last kernel stop
         const float *km = res->kernel_ms;

@@ -227,15 +227,19 @@ int pmap_index_build_host(const pmap_index_desc_t *d, pmap_index *idx) {
         while (idx->slots[s].key != PMAP_EMPTY_KEY) s = (s + 1) & capmask;
         idx->slots[s] = PmapSlot{ukeys[i], uoff[i], ucnt[i], idx->recs[uoff[i]]};
     }
-    // presence filter: 8 bits per slot (16 per key at most), at most 2^24 bits (2 MiB) so that it stays
-    // in the L2 of every XCD; two bits per key once one bit per key would fill more than 1/16 of it;
-    // pointless once the keys outnumber a quarter of the bits
-    uint32_t max_fbits = 24;
-    if (const char *cap_env = getenv("PMAP_FILTER_MAX_BITS")) {      // tests: every filter mode with a small index
+    // presence filter: 8 to 16 bits per key, two of them set per key, while that takes at most 2^24 bits (2 MiB);
+    // 2^23 bits (1 MiB) when that still leaves 6 bits per key: the filter shares the 4 MiB L2 of an XCD with the
+    // table lines and tile entries that stream through it, and a filter line that has left the L2 costs as much
+    // as the table read it might have saved (measured, 1.1 M keys and every k-mer a lookup: 2^24 bits 33.9,
+    // 2^23 bits 35.4 Gbases/s; 158 000 keys: 2^22 bits 521, 2^21 536, 2^20 515 Gbases/s); one bit per key while
+    // one bit per key fills at most 1/16 of the filter; pointless once the keys outnumber a quarter of the bits
+    uint32_t fbits = 6;
+    while ((1ull << fbits) < 8 * idx->n_keys && fbits < 24) ++fbits;
+    if (fbits == 24 && idx->n_keys * 6 <= (1ull << 23)) fbits = 23;
+    if (const char *cap_env = getenv("PMAP_FILTER_MAX_BITS")) {      // tests, sweeps: 8 bits per slot, at most so many
         const int v = atoi(cap_env);
-        if (v >= 6 && v <= 30) max_fbits = (uint32_t) v;
+        if (v >= 6 && v <= 30) fbits = std::min<uint32_t>(log2cap + 3, (uint32_t) v);
     }
-    uint32_t fbits = std::min<uint32_t>(log2cap + 3, max_fbits);
     if (idx->n_keys * 4 > (1ull << fbits)) fbits = 0;
     else if (idx->n_keys * 16 > (1ull << fbits)) fbits |= PMAP_FILTER_TWO;
     // Too many keys for a filter of that size: a bitmap over the whole key range when that has at most 2^30

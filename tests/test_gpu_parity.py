@@ -401,6 +401,39 @@ def test_wavefront_sort_comes_and_goes(gpu):
     gidx.close()
 
 
+def test_few_hits_per_read_switch_tails(gpu):
+    """A result object whose last batch had fewer than 16 hits per read (many short reads under a sparse sketch)
+    maps the next batch with the separate sort and cluster kernels, and goes back to the fused tail kernel after
+    a batch with more hits per read; same hits and clusters as the oracle each time."""
+    from parity import _check_hits_and_clusters, oracle_index
+    rng = np.random.default_rng(91)
+    loci = synth.make_loci(30, rng)
+    genome = synth.make_genome(loci, rng)
+    si = synth.build_index(loci, 14, 15)
+    few = synth.simulate_reads(genome, 1500, rng, fixed_len=150, e_rate=0.001)
+    many = synth.simulate_reads(genome, 1100, rng, fixed_len=700, e_rate=0.001)
+    gidx = gpu_index(si)
+    frac = api.fraction(0.001, 15)
+    res = None
+    tails = []
+    for bases, off in (few, few, many, many, few):
+        ids = np.arange(len(off) - 1, dtype=np.uint32)
+        orc = O.oracle_map(oracle_index(si), bases, off, ids, 14, 15, 31, frac, 3, 30, si.min_path_length)
+        rd = api.Reads(bases, off)
+        res = api.map_reads(gidx, rd, 14, 15, 31, frac, min_cluster_size=3, expected_kmers=30, result=res, profile=1)
+        cn = res.counts()
+        _check_hits_and_clusters(res, cn, orc)
+        per_read = cn["n_hits"] / (len(off) - 1)
+        assert (per_read < 16) == (bases is few[0]), per_read
+        ms = res.kernel_ms()
+        tails.append("separate" if ms.get("sort_rank", 0) > 0 else "fused")
+        assert (ms.get("tail", 0) > 0) != (ms.get("sort_rank", 0) > 0), ms
+        rd.close()
+    assert tails == ["fused", "separate", "separate", "fused", "fused"], tails
+    res.close()
+    gidx.close()
+
+
 def test_chained_scan_fallback(gpu):
     """When a chained prefix sum of the cluster kernels gives up waiting, the batch is mapped again with one
     workgroup per kernel that carries the prefix itself; same clusters.  The test hook makes the chain give up

@@ -231,7 +231,7 @@ def test_presence_filter_choice(tmp_path, monkeypatch):
         i = idx.info()
         return idx, (i["filter_bits"], i["filter_bits_per_key"], i["filter_direct"])
 
-    assert info(si14)[1][1:] == (1, 0)                    # few keys: hashed, one bit per key
+    assert info(si14)[1][1:] == (2, 0)                    # few keys: hashed, 8 to 16 bits per key, two of them set
     monkeypatch.setenv("PMAP_FILTER_MAX_BITS", "12")      # as if the keys outnumbered what a hashed filter takes
     idx, got = info(si14)
     assert got == (30, 1, 1)
