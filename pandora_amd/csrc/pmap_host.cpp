@@ -312,16 +312,60 @@ struct PgHit {
     uint32_t pos, rec, rank;
 };
 
-struct PgRead {
-    std::vector<uint32_t> nodes;
-    std::vector<uint8_t> orient;
+// A run of add_node calls and what they leave in pangenome::Graph::reads.  The read loop numbers the reads in
+// file order and a read's calls come together (clusterComp orders by read first), so the reads are kept in rising
+// id order: read i has the nodes rn_prg / rn_orient [read_start[i], read_start[i + 1]), the last one up to the end.
+struct PgCalls {
+    std::vector<uint32_t> call_prg, call_read, call_size;
+    std::vector<uint8_t> call_fwd;
+    std::vector<uint32_t> read_ids;
+    std::vector<uint64_t> read_start;
+    std::vector<uint32_t> rn_prg;
+    std::vector<uint8_t> rn_orient;
+
+    // pangenome::Graph::add_node (src/pangenome/pangraph.cpp:126-140) with record_read_info (:108-122); the
+    // node's own part, get_node (:59-76) and covg, is counted from the calls when it is asked for
+    void add(uint32_t prg, uint32_t read, uint32_t size, bool first_fwd) {
+        if (read_ids.empty() || read_ids.back() != read) {
+            read_ids.push_back(read);
+            read_start.push_back(rn_prg.size());
+        }
+        const uint8_t orientation = size > 0 && first_fwd;
+        if (rn_prg.size() == read_start.back() || rn_prg.back() != prg || rn_orient.back() != orientation) {
+            rn_prg.push_back(prg);
+            rn_orient.push_back(orientation);
+        }
+        call_prg.push_back(prg);
+        call_read.push_back(read);
+        call_size.push_back(size);
+        call_fwd.push_back(first_fwd);
+    }
+    // the calls of a later stretch of the file
+    void append(const PgCalls &o) {
+        size_t c0 = 0, r0 = 0, n0 = 0;      // calls, reads and read nodes of `o` that go through add()
+        if (!o.read_ids.empty() && !read_ids.empty() && read_ids.back() == o.read_ids.front()) {
+            // (a read never spans two batches; if one did, its calls would go on as add() has them)
+            for (; c0 < o.call_read.size() && o.call_read[c0] == o.read_ids.front(); ++c0)
+                add(o.call_prg[c0], o.call_read[c0], o.call_size[c0], o.call_fwd[c0] != 0);
+            r0 = 1;
+            n0 = o.read_start.size() > 1 ? (size_t) o.read_start[1] : o.rn_prg.size();
+        }
+        const uint64_t shift = (uint64_t) rn_prg.size() - n0;
+        read_ids.insert(read_ids.end(), o.read_ids.begin() + r0, o.read_ids.end());
+        for (size_t i = r0; i < o.read_start.size(); ++i) read_start.push_back(o.read_start[i] + shift);
+        rn_prg.insert(rn_prg.end(), o.rn_prg.begin() + n0, o.rn_prg.end());
+        rn_orient.insert(rn_orient.end(), o.rn_orient.begin() + n0, o.rn_orient.end());
+        call_prg.insert(call_prg.end(), o.call_prg.begin() + c0, o.call_prg.end());
+        call_read.insert(call_read.end(), o.call_read.begin() + c0, o.call_read.end());
+        call_size.insert(call_size.end(), o.call_size.begin() + c0, o.call_size.end());
+        call_fwd.insert(call_fwd.end(), o.call_fwd.begin() + c0, o.call_fwd.end());
+    }
 };
 
-struct pmap_pangraph {
-    std::map<uint32_t, uint32_t> node_covg;   // node id (= prg id) -> covg
-    std::map<uint32_t, PgRead> reads;
-    PgRead *last_read = nullptr;      // the entry of `last_read_id` (map nodes do not move): calls come grouped by read
-    uint32_t last_read_id = 0;
+struct pmap_pangraph : PgCalls {
+    // pangenome::Graph::nodes: node id (= prg id) -> covg, the number of calls that named it; counted on demand
+    std::map<uint32_t, uint32_t> node_covg;
+    bool nodes_valid = false;
     // Read::hits in add_node call order, each call's cluster in pComp order: one segment per mapped batch, kept as
     // the mapper thread made it (copying 10^7 records once more on the retiring thread made that thread the slow
     // one); `flat` = the segments in one array, made when hits are asked for by global index
@@ -329,8 +373,6 @@ struct pmap_pangraph {
     size_t n_hits = 0;
     std::vector<PgHit> flat;
     bool flat_valid = false;
-    std::vector<uint32_t> call_prg, call_read, call_size;
-    std::vector<uint8_t> call_fwd;
     bool keep_hits = true;
     std::vector<uint64_t> by_path;    // hits in Read::hits order (indices into `hits`), built on demand
     std::vector<uint32_t> hit_call;   // the call of every hit, built with by_path
@@ -339,26 +381,16 @@ struct pmap_pangraph {
     std::vector<uint32_t> cov_fwd, cov_rev;
 };
 
-// pangenome::Graph::add_node (src/pangenome/pangraph.cpp:126-140) with get_node (:59-76) and
-// record_read_info (:108-122)
-static void pg_add_node(pmap_pangraph *pg, uint32_t prg, uint32_t read, uint32_t size, bool first_fwd) {
-    auto it = pg->node_covg.find(prg);
-    if (it == pg->node_covg.end()) pg->node_covg[prg] = 1; else it->second += 1;
-    // (read ids arrive in rising order, one read's calls together: the entry is the last one used or a new last one)
-    if (!pg->last_read || pg->last_read_id != read) {
-        pg->last_read = &pg->reads.emplace_hint(pg->reads.end(), read, PgRead())->second;
-        pg->last_read_id = read;
-    }
-    PgRead &r = *pg->last_read;
-    const uint8_t orientation = size > 0 && first_fwd;
-    if (r.nodes.empty() || r.nodes.back() != prg || r.orient.back() != orientation) {
-        r.nodes.push_back(prg);
-        r.orient.push_back(orientation);
-    }
-    pg->call_prg.push_back(prg);
-    pg->call_read.push_back(read);
-    pg->call_size.push_back(size);
-    pg->call_fwd.push_back(first_fwd);
+static void pg_count_nodes(pmap_pangraph *pg) {
+    if (pg->nodes_valid) return;
+    pg->node_covg.clear();
+    uint32_t top = 0;
+    for (uint32_t p : pg->call_prg) top = std::max(top, p);
+    std::vector<uint32_t> n(pg->call_prg.empty() ? 0 : (size_t) top + 1, 0);
+    for (uint32_t p : pg->call_prg) n[p]++;
+    for (size_t p = 0; p < n.size(); ++p)
+        if (n[p]) pg->node_covg.emplace_hint(pg->node_covg.end(), (uint32_t) p, n[p]);
+    pg->nodes_valid = true;
 }
 
 static void pg_flatten_hits(pmap_pangraph *pg) {
@@ -763,9 +795,7 @@ struct ReadLoop {
     }
 };
 
-struct Outcome {           // what one mapped batch contributes to the pangraph
-    std::vector<uint32_t> prg, read, size;
-    std::vector<uint8_t> fwd;
+struct Outcome : PgCalls {  // what one mapped batch contributes to the pangraph
     std::vector<PgHit> hits;        // call order, each call's cluster in pComp order
 };
 
@@ -1178,10 +1208,7 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool
     for (size_t j = 0; j < nc; ++j) {
         if (!alive[j]) continue;
         const uint64_t c = order[j];
-        out->prg.push_back(prg[c]);
-        out->read.push_back(rid[c]);
-        out->size.push_back(size[c]);
-        out->fwd.push_back(fwd[c]);
+        out->add(prg[c], rid[c], size[c], fwd[c] != 0);       // src/utils.cpp:346-351
         if (keep_hits)
             for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
                 out->hits.push_back(PgHit{hpos[i], hrec[i], idx->path_rank[hrec[i]]});
@@ -1416,7 +1443,7 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
             pl.done.erase(next);
         }
         pl.cv.notify_all();
-        for (size_t j = 0; j < o->prg.size(); ++j) pg_add_node(pg, o->prg[j], o->read[j], o->size[j], o->fwd[j] != 0);
+        pg->append(*o);     // (the mapper thread has made the calls: here they only join those of the batches before)
         if (!o->hits.empty()) {
             pg->n_hits += o->hits.size();
             pg->hit_seg.push_back(std::move(o->hits));
@@ -1433,6 +1460,7 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     for (auto &t : threads) t.join();
     pg->by_path_valid = false;
     pg->flat_valid = false;
+    pg->nodes_valid = false;
     if (getenv("PMAP_TRACE_PIPELINE"))
         fprintf(stderr, "[pmap] read-file pipeline: %.3f s, %s, %zu mapping contexts; waited: sequencer for pieces %.3f s, "
                         "mappers for batches %.3f s (all of them together), retiring thread for mapped batches %.3f s; "
@@ -1463,10 +1491,10 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
 
 extern "C" int pmap_pangraph_info(const pmap_pangraph_t *pg, pmap_pangraph_info_t *info) {
     if (!pg || !info) return pmap_fail(PMAP_EINVAL, "null argument");
+    pg_count_nodes(const_cast<pmap_pangraph *>(pg));
     info->n_nodes = (uint32_t) pg->node_covg.size();
-    info->n_reads = (uint32_t) pg->reads.size();
-    info->n_read_nodes = 0;
-    for (auto &r : pg->reads) info->n_read_nodes += r.second.nodes.size();
+    info->n_reads = (uint32_t) pg->read_ids.size();
+    info->n_read_nodes = pg->rn_prg.size();
     info->n_hits = pg->n_hits;
     info->n_add_node_calls = pg->call_prg.size();
     return PMAP_OK;
@@ -1474,6 +1502,7 @@ extern "C" int pmap_pangraph_info(const pmap_pangraph_t *pg, pmap_pangraph_info_
 
 extern "C" int pmap_pangraph_nodes(const pmap_pangraph_t *pg, uint32_t *prg_id, uint32_t *covg) {
     if (!pg) return pmap_fail(PMAP_EINVAL, "null argument");
+    pg_count_nodes(const_cast<pmap_pangraph *>(pg));
     size_t i = 0;
     for (auto &n : pg->node_covg) {
         if (prg_id) prg_id[i] = n.first;
@@ -1486,18 +1515,11 @@ extern "C" int pmap_pangraph_nodes(const pmap_pangraph_t *pg, uint32_t *prg_id, 
 extern "C" int pmap_pangraph_reads(const pmap_pangraph_t *pg, uint32_t *read_id, uint64_t *node_off,
                                    uint32_t *node_prg, uint8_t *node_orientation) {
     if (!pg) return pmap_fail(PMAP_EINVAL, "null argument");
-    size_t i = 0;
-    uint64_t o = 0;
-    for (auto &r : pg->reads) {
-        if (read_id) read_id[i] = r.first;
-        if (node_off) node_off[i] = o;
-        for (size_t j = 0; j < r.second.nodes.size(); ++j) {
-            if (node_prg) node_prg[o] = r.second.nodes[j];
-            if (node_orientation) node_orientation[o] = r.second.orient[j];
-            ++o;
-        }
-        ++i;
-    }
+    const size_t i = pg->read_ids.size(), o = pg->rn_prg.size();
+    if (read_id && i) memcpy(read_id, pg->read_ids.data(), sizeof(uint32_t) * i);
+    if (node_off && i) memcpy(node_off, pg->read_start.data(), sizeof(uint64_t) * i);
+    if (node_prg && o) memcpy(node_prg, pg->rn_prg.data(), sizeof(uint32_t) * o);
+    if (node_orientation && o) memcpy(node_orientation, pg->rn_orient.data(), o);
     if (node_off) node_off[i] = o;
     return PMAP_OK;
 }
