@@ -383,8 +383,9 @@ typedef struct {
  * into pieces and parse them side by side (gzip input: one sequential reader),
  * one sequencer applies the read loop's rules in file order, one mapper thread
  * per mapping context (pmap_init_devices; by default three contexts on the
- * calling thread's GPU) uploads and maps whole batches, and the calling thread
- * retires the batches in file order; the call returns when the file is done. */
+ * calling thread's GPU) uploads and maps whole batches, runs filter_clusters
+ * and lists the batch's add_node calls, and the calling thread joins the
+ * batches in file order; the call returns when the file is done. */
 int pmap_pangraph_from_read_file(const char *reads_path, const pmap_index_t *idx, const pmap_map_args_t *args,
                                  pmap_pangraph_t **out, uint32_t *covg);
 
@@ -422,6 +423,11 @@ int pmap_pangraph_call_hits(const pmap_pangraph_t *pg, uint64_t *hit_off, uint32
  * reverse hits, n_records entries each in the caller's record numbering. */
 int pmap_pangraph_coverage(const pmap_pangraph_t *pg, uint32_t *forward, uint32_t *reverse);
 void pmap_pangraph_destroy(pmap_pangraph_t *pg);
+/* pmap_pangraph_from_read_file keeps the page-locked host buffers of its batches
+ * for its next call (at most 1 GiB; PMAP_PINNED_CACHE_BYTES in the environment
+ * sets another bound, 0 keeps none).  This frees the ones not in use and returns
+ * their bytes.  (No counterpart in the reference, which has no device buffers.) */
+uint64_t pmap_release_host_cache(void);
 
 #ifdef __cplusplus
 }

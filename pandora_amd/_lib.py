@@ -110,6 +110,7 @@ SIGNATURES = {
     "pmap_pangraph_call_hits": (C.c_int, [C.c_void_p, u64p, u32p, u32p]),
     "pmap_pangraph_coverage": (C.c_int, [C.c_void_p, u32p, u32p]),
     "pmap_pangraph_destroy": (None, [C.c_void_p]),
+    "pmap_release_host_cache": (C.c_uint64, []),
     "pmap_reads_update": (C.c_int, [C.c_void_p, C.c_char_p, u64p, C.c_uint32, C.c_uint32]),
     "pmap_pack_reads": (C.c_int, [C.c_char_p, u64p, C.c_uint32, u32p, u8p]),
     "pmap_reads_create_packed": (C.c_int, [u32p, u64p, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -230,7 +230,7 @@ extern "C" int pmap_init_devices(const int *devices, int n_devices) {
 
 static int ensure_init();
 
-// The contexts pmap_pangraph_from_read_file works with: those of pmap_init_devices, or, by default, two on
+// The contexts pmap_pangraph_from_read_file works with: those of pmap_init_devices, or, by default, three on
 // the calling thread's GPU (made on first use and kept).
 int pmap_contexts_for_file(std::vector<void *> *out) {
     int rc = ensure_init();
@@ -241,8 +241,10 @@ int pmap_contexts_for_file(std::vector<void *> *out) {
         for (DevCtx *c : g_pool) out->push_back(c);
     }
     if (!out->empty()) return PMAP_OK;
-    // no list from pmap_init_devices: FILE_CONTEXTS contexts on the calling thread's GPU, its own among them (two
-    // mapper threads are busy 90 % of the time at 15 Gbases/s of FASTQ; with three the parser threads are the limit)
+    // no list from pmap_init_devices: FILE_CONTEXTS contexts on the calling thread's GPU, its own among them (a
+    // mapper thread spends more time waiting for its batch than working on it: 1.5 ms per batch of 32 Mbases for
+    // upload, map and filter_clusters; with three of them the parser threads are the limit at 50 Gbases/s of
+    // FASTQ on 16 cores, with two 45)
     static const size_t FILE_CONTEXTS = 3;
     DevCtx *mine = t_ctx;
     out->push_back(mine);
@@ -450,27 +452,47 @@ static int new_result(pmap_result **out);
 // ---------------------------------------------------------------------------
 // index upload
 
+// The index's copy on the calling thread's GPU, made on first use.  Every caller comes through here (and so
+// through upload_mu) before it reads the device pointers: several mapper threads share one index.
 int pmap_index_upload(pmap_index *idx) {
     int rc = ensure_init();
     if (rc) return rc;
     pmap_index::OnDevice &od = idx->dev[t_ctx->device];
     std::lock_guard<std::mutex> l(idx->upload_mu);
     if (od.slots) return PMAP_OK;
-    size_t sb = idx->slots.size() * sizeof(PmapSlot), rb = (idx->recs.size() + 1) * sizeof(PmapRec);
-    HIP_TRY(hipMalloc((void **) &od.recs, rb));
-    if (!idx->recs.empty())
-        HIP_TRY(hipMemcpy(od.recs, idx->recs.data(), idx->recs.size() * sizeof(PmapRec), hipMemcpyHostToDevice));
+    const size_t sb = idx->slots.size() * sizeof(PmapSlot), rb = (idx->recs.size() + 1) * sizeof(PmapRec);
     const size_t fb = idx->filter.size() * sizeof(uint32_t);
-    if (fb) {
-        HIP_TRY(hipMalloc((void **) &od.filter, fb));
-        HIP_TRY(hipMemcpy(od.filter, idx->filter.data(), fb, hipMemcpyHostToDevice));
-    }
     PmapSlot *slots = nullptr;
-    HIP_TRY(hipMalloc((void **) &slots, sb));
-    HIP_TRY(hipMemcpy(slots, idx->slots.data(), sb, hipMemcpyHostToDevice));
+    auto upload = [&]() -> int {
+        HIP_TRY(hipMalloc((void **) &od.recs, rb));
+        if (!idx->recs.empty())
+            HIP_TRY(hipMemcpy(od.recs, idx->recs.data(), idx->recs.size() * sizeof(PmapRec), hipMemcpyHostToDevice));
+        if (fb) {
+            HIP_TRY(hipMalloc((void **) &od.filter, fb));
+            HIP_TRY(hipMemcpy(od.filter, idx->filter.data(), fb, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMalloc((void **) &slots, sb));
+        HIP_TRY(hipMemcpy(slots, idx->slots.data(), sb, hipMemcpyHostToDevice));
+        return PMAP_OK;
+    };
+    if ((rc = upload())) {
+        // nothing of a copy that did not complete stays behind: the next call starts over
+        if (od.recs) (void) hipFree(od.recs);
+        if (od.filter) (void) hipFree(od.filter);
+        if (slots) (void) hipFree(slots);
+        od.recs = nullptr;
+        od.filter = nullptr;
+        return rc;
+    }
     od.slots = slots;       // last: a set `slots` says the whole copy is there
     idx->device_bytes = sb + rb + fb;
     return PMAP_OK;
+}
+
+// (for callers that must not allocate)
+static bool index_is_on_device(const pmap_index *idx, int device) {
+    std::lock_guard<std::mutex> l(const_cast<pmap_index *>(idx)->upload_mu);
+    return idx->dev[device].slots != nullptr;
 }
 
 extern "C" int pmap_index_upload_now(pmap_index_t *idx) {
@@ -1112,7 +1134,7 @@ extern "C" int pmap_map_async(const pmap_index_t *idx, const pmap_reads_t *rd, c
     // the batch's context decides where the call runs
     DevCtx *ctx = rd->ctx;
     if ((rc = bind(ctx))) return rc;
-    if (!idx->dev[ctx->device].slots && (rc = pmap_index_upload(const_cast<pmap_index *>(idx)))) return rc;
+    if ((rc = pmap_index_upload(const_cast<pmap_index *>(idx)))) return rc;
     pmap_result *res = *result;
     if (res && res->ctx != ctx)
         return pmap_fail(PMAP_EINVAL, "the result object belongs to another mapping context than the reads");
@@ -1371,7 +1393,7 @@ extern "C" int pmap_map_noalloc(const pmap_index_t *idx, const pmap_reads_t *rd,
     if (prm->w < 1 || prm->w > (uint32_t) SK_MAX_W) return pmap_fail(PMAP_EINVAL, "w must be in [1,64]");
     if ((prm->flags & PMAP_FLAG_UNFUSED) || (prm->last_stage && prm->last_stage != PMAP_STAGE_CLUSTER))
         return pmap_fail(PMAP_EINVAL, "pmap_map_noalloc runs the whole path in its default mode only");
-    if (!idx->dev[ctx->device].slots)
+    if (!index_is_on_device(idx, ctx->device))
         return pmap_fail(PMAP_EINVAL, "the index is not on the device: call pmap_index_upload_now first (this entry point does not allocate)");
     if (!out->hit_read || !out->hit_key || !out->hit_pos || !out->hit_rank || !out->hit_rec || !out->cluster_rows)
         return pmap_fail(PMAP_EINVAL, "null output buffer");

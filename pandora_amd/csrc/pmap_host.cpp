@@ -455,11 +455,14 @@ double now_s() {
 }
 
 // Pinned buffers are expensive to make (the driver locks and maps every page): the ones a call is done with
-// are kept for the next call, up to 4 GiB of them.
+// are kept for the next call, up to 1 GiB of them (PMAP_PINNED_CACHE_BYTES: another bound, 0 keeps none; a call
+// of pmap_pangraph_from_read_file on a plain file uses about 20 buffers of 8 MiB).  pmap_release_host_cache()
+// gives them back.
 struct PinnedCache {
     std::mutex m;
     std::vector<std::pair<char *, size_t>> free_list;
     size_t held = 0;
+    size_t cap = getenv("PMAP_PINNED_CACHE_BYTES") ? (size_t) strtoull(getenv("PMAP_PINNED_CACHE_BYTES"), nullptr, 10) : (size_t) 1 << 30;
     char *take(size_t want, size_t *got) {
         std::lock_guard<std::mutex> l(m);
         size_t best = free_list.size();
@@ -475,10 +478,24 @@ struct PinnedCache {
     }
     bool give(char *p, size_t bytes) {       // false: not kept, the caller frees it
         std::lock_guard<std::mutex> l(m);
-        if (bytes < (1u << 20) || held + bytes > (4ull << 30)) return false;
+        if (bytes < (1u << 20) || held + bytes > cap) return false;
         free_list.push_back({p, bytes});
         held += bytes;
         return true;
+    }
+    size_t release_all() {
+        std::vector<std::pair<char *, size_t>> mine;
+        {
+            std::lock_guard<std::mutex> l(m);
+            mine.swap(free_list);
+            held = 0;
+        }
+        size_t bytes = 0;
+        for (auto &b : mine) {
+            pmap_pinned_free(b.first);
+            bytes += b.second;
+        }
+        return bytes;
     }
 };
 PinnedCache g_pinned_cache;
@@ -1325,6 +1342,8 @@ bool looks_gzipped(const char *path) {
 }
 
 }  // namespace
+
+extern "C" uint64_t pmap_release_host_cache(void) { return g_pinned_cache.release_all(); }
 
 extern "C" int pmap_pack_reads(const char *bases, const uint64_t *offsets, uint32_t n_reads, uint32_t *packed,
                                uint8_t *acgt_only) {

@@ -244,6 +244,11 @@ def test_presence_filter_choice(tmp_path, monkeypatch):
     assert (i["filter_bits"], i["filter_bits_per_key"], i["filter_direct"]) == (30, 1, 1)
 
 
+def test_release_host_cache_without_buffers():
+    """Nothing page-locked is kept before any read file has been mapped."""
+    assert _lib.load().pmap_release_host_cache() == 0
+
+
 def test_gfa_min_path_length(tmp_path):
     cases = list(RC.BIGGER_INFER["graphs"].values()) + list(RC.SIMPLE_INFER["graphs"].values())
     for i, (paths, edges) in enumerate(cases):
