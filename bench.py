@@ -376,6 +376,9 @@ def main():
     ap.add_argument("--file-copies", type=int, default=40, help="--mode file: the workload's reads this many times over")
     ap.add_argument("--file-contexts", type=int, default=0, help="--mode file: mapping contexts per GPU (0 = the library's default for one GPU, one per GPU otherwise)")
     ap.add_argument("--file-keep-hits", action="store_true", help="--mode file: keep Read::hits")
+    ap.add_argument("--alone-steps", type=int, default=200,
+                    help="steps of the second, untimed pass that times every kernel with the machine to itself (at least 1; "
+                         "1 under a kernel trace, so that the trace's averages are those of the timed region)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events at all inside the timed steps; all kernel times come from the second pass")
     args = ap.parse_args()
@@ -451,7 +454,7 @@ def main():
     # second, untimed pass with events on every kernel, for the per-phase table: one step at a time, every
     # kernel with the machine to itself (in the timed region the sketch kernels of two steps and the tail
     # kernels of a third share the CUs, so a launch lasts longer there)
-    kernel_ms, res = kernel_table(wl, res, min(args.steps, 200))
+    kernel_ms, res = kernel_table(wl, res, max(1, min(args.steps, args.alone_steps)))
     sketch_alone_ms = kernel_ms.get("sketch", 0.0)
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -507,6 +510,10 @@ def main():
                 roofline["achieved_all_launches"] = algo[dom] * args.steps / elapsed_local / 1e9
             if valu:
                 valu["frac_alone"] = valu["wave_insts_per_launch"] / (sketch_alone_ms * 1e-3) / VALU_PEAK_WAVE_INSTS
+                # a kernel far below the VALU issue rate with the machine to itself waits for its index lookups:
+                # requests beyond the L2, which the chip serves at about 55 G per second whatever their size
+                if valu["frac_alone"] < 0.6:
+                    roofline["limited_by"] = "memory requests beyond the L2 (index lookups)"
         total_algo = sum(algo.values())
         out = {
             "metric": "read bases mapped/sec (sketch+probe+cluster)",

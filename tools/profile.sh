@@ -4,7 +4,8 @@ tag=$1; wl=$2; steps=${3:-100}
 root=$(pwd); out=$root/gpurun_out/prof; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 common="--steps $steps --no-cpu-baseline --others none --workload $wl"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${wl}_kt -o kt -- python3 $root/bench.py $common > $out/${tag}_${wl}_bench_under_rocprof.json 2> $out/${tag}_${wl}_kt.err || { echo "kernel trace failed"; tail -5 $out/${tag}_${wl}_kt.err; exit 1; }
+# (one step of the pass that times kernels alone: the trace's averages are those of the timed region and its warm-up)
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${wl}_kt -o kt -- python3 $root/bench.py $common --alone-steps 1 > $out/${tag}_${wl}_bench_under_rocprof.json 2> $out/${tag}_${wl}_kt.err || { echo "kernel trace failed"; tail -5 $out/${tag}_${wl}_kt.err; exit 1; }
 find $out/${tag}_${wl}_kt -name "*kernel_stats.csv" -exec cp {} $out/${tag}_${wl}_kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES"; do
   name=$(echo $c | cut -d' ' -f1)
