@@ -208,6 +208,67 @@ def timed_steps(wl, steps, depth, prof, ring, before=None, after=None):
     return elapsed, sketch_ms, ring[(steps - 1) % depth] if steps else ring[0]
 
 
+def upload_variants(wl, step_s):
+    """What it costs to bring one batch to the device (copy + encode kernels, buffers in place): letters or 2-bit
+    words packed on the host beforehand, from pageable or page-locked host memory.  Each is the best of three
+    pmap_reads_update* calls on a reads object of its own; bases_per_s adds one step of the timed region."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from pandora_amd import _lib
+    lib = _lib.load()
+    u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    bases = np.ascontiguousarray(wl.bases, np.uint8)
+    offsets = np.ascontiguousarray(wl.offsets, np.uint64)
+    n, n_bases = len(offsets) - 1, int(offsets[-1] - offsets[0])
+    lens = np.diff(offsets.astype(np.int64))
+    words = np.zeros(int(((lens + 15) // 16).sum()) + 1, np.uint32)
+    ok = np.zeros(n + 1, np.uint8)
+    t0 = time.perf_counter()
+    if lib.pmap_pack_reads(bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(u64p), n, words.ctypes.data_as(u32p),
+                           ok.ctypes.data_as(u8p)):
+        return None
+    pack_s = time.perf_counter() - t0
+
+    def pinned(a):
+        t = torch.empty(a.shape, dtype=torch.uint8 if a.dtype == np.uint8 else torch.int32, pin_memory=True)
+        v = t.numpy().view(a.dtype)
+        v[...] = a
+        return t, v
+
+    keep = []
+    out = {"host_pack_s_one_thread": pack_s}
+    for name, packed, pin in (("letters_pageable", False, False), ("letters_pinned", False, True),
+                              ("packed_pageable", True, False), ("packed_pinned", True, True)):
+        src = words if packed else bases
+        if pin:
+            t, src = pinned(src)
+            keep.append(t)
+        h = C.c_void_p()
+        if packed:
+            args = (src.ctypes.data_as(u32p), offsets.ctypes.data_as(u64p), ok.ctypes.data_as(u8p), n, 0)
+            rc = lib.pmap_reads_create_packed(*args, C.byref(h))
+            update = lambda: lib.pmap_reads_update_packed(h, *args)
+        else:
+            args = (src.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(u64p), n, 0)
+            rc = lib.pmap_reads_create(*args, C.byref(h))
+            update = lambda: lib.pmap_reads_update(h, *args)
+        if rc:
+            return None
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            if update():
+                return None
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        lib.pmap_reads_destroy(h)
+        out[name] = {"upload_s": best, "bases_per_s": n_bases / (best + step_s)}
+    return out
+
+
 def kernel_table(wl, res, steps):
     """Per-kernel milliseconds per step from an untimed pass with events on every kernel, one step at a time
     (each kernel with the machine to itself)."""
@@ -546,9 +607,13 @@ def main():
                            "frac_of_hbm_peak": total_algo / (elapsed_local / steps) / 1e9 / HBM_PEAK_GBS},
             **(step_traffic(args.workload, elapsed_local / steps * 1e3) if args.scale == 1.0 else {}),
             "upload_and_encode_s": wl.upload_s,
-            "end_to_end": {"note": "one batch from pageable host memory as ASCII: upload + encode + one step",
+            "end_to_end": {"note": "one batch from pageable host memory as ASCII: upload + encode + one step (the first "
+                                   "upload of the process, device buffers made on the way); variants: the same with "
+                                   "the buffers in place, letters or words packed on the host, pageable or pinned",
                            "bases_per_s": cn["n_bases"] / (wl.upload_s + elapsed_local / steps)},
         }
+        if world == 1:
+            out["end_to_end"]["variants"] = upload_variants(wl, elapsed_local / steps)
         if world == 1 and not args.no_cpu_baseline:
             progress("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(si, wl.bases, wl.offsets, prm, wl.fraction)
