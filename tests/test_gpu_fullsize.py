@@ -187,13 +187,13 @@ def _check_full_size(name, slices, min_reads, min_minimizers, min_hits):
 
 
 def test_illumina_w1_full_size(gpu):
-    """BASELINE's Illumina configuration at the bench's full size: 200 000 reads of 150 bases, w = 1 (every k-mer is
+    """The benchmark's Illumina configuration at its full size: 200 000 reads of 150 bases, w = 1 (every k-mer is
     looked up), 13 M hits."""
     _check_full_size("illumina_w1", ((0, 1200), (123456, 1200)), 200000, 2.5e7, 1e7)
 
 
 def test_illumina_20k_w1_full_size(gpu):
-    """BASELINE's Illumina configuration on the 20 000-locus index it names, at the bench's full size: a w = 1 index
+    """The benchmark's Illumina configuration on its 20 000-locus index, at full size: a w = 1 index
     of 22.6 M keys spread evenly over the key range (2 GB table, no presence filter), 400 000 reads of 150 bases,
     every k-mer looked up, 29 M hits; the reference's thresholds (src/map_main.cpp:267-272, src/utils.cpp:413-416)
     reject every cluster."""

@@ -1,4 +1,4 @@
-"""usage: tools/bench_table.py BENCH.json: the per-workload table of DESIGN.md from one bench.py line."""
+"""usage: tools/bench_table.py BENCH.json: one bench.py line as a markdown table, a row per workload."""
 import json
 import sys
 
