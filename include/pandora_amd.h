@@ -56,7 +56,7 @@ int pmap_init(int device);
  * read file over: one per entry of `devices`, in this order; a GPU may be
  * listed more than once (two contexts on one GPU overlap the upload of one
  * batch with the kernels and the host work of another).  n = 0 goes back to
- * the default, three contexts on the calling thread's GPU.  No counterpart in
+ * the default, four contexts on the calling thread's GPU.  No counterpart in
  * the reference, which is single-threaded: results do not depend on it. */
 int pmap_init_devices(const int *devices, int n);
 
@@ -382,7 +382,7 @@ typedef struct {
  * function's return value.  Inside the call, parser threads cut a plain file
  * into pieces and parse them side by side (gzip input: one sequential reader),
  * one sequencer applies the read loop's rules in file order, one mapper thread
- * per mapping context (pmap_init_devices; by default three contexts on the
+ * per mapping context (pmap_init_devices; by default four contexts on the
  * calling thread's GPU) uploads and maps whole batches, runs filter_clusters
  * and lists the batch's add_node calls, and the calling thread joins the
  * batches in file order; the call returns when the file is done. */

@@ -230,7 +230,7 @@ extern "C" int pmap_init_devices(const int *devices, int n_devices) {
 
 static int ensure_init();
 
-// The contexts pmap_pangraph_from_read_file works with: those of pmap_init_devices, or, by default, three on
+// The contexts pmap_pangraph_from_read_file works with: those of pmap_init_devices, or, by default, four on
 // the calling thread's GPU (made on first use and kept).
 int pmap_contexts_for_file(std::vector<void *> *out) {
     int rc = ensure_init();
@@ -242,10 +242,11 @@ int pmap_contexts_for_file(std::vector<void *> *out) {
     }
     if (!out->empty()) return PMAP_OK;
     // no list from pmap_init_devices: FILE_CONTEXTS contexts on the calling thread's GPU, its own among them (a
-    // mapper thread spends more time waiting for its batch than working on it: 1.5 ms per batch of 32 Mbases for
-    // upload, map and filter_clusters; with three of them the parser threads are the limit at 50 Gbases/s of
-    // FASTQ on 16 cores, with two 45)
-    static const size_t FILE_CONTEXTS = 3;
+    // mapper thread spends more time on the host side of its batch than the GPU spends mapping it: per batch of
+    // 32 Mbases 0.4 ms upload, 0.26 ms map, 0.7 ms for the kept clusters and filter_clusters, and 1.2 ms more for
+    // Read::hits when they are kept.  On 16 cores, without hits: 3, 4, 5 contexts 50 Gbases/s of FASTQ, the
+    // parser threads being the limit, 6 contexts 47.5; with hits: 3 contexts 28, 4 contexts 34, 5 and 6 contexts 33)
+    static const size_t FILE_CONTEXTS = 4;
     DevCtx *mine = t_ctx;
     out->push_back(mine);
     {

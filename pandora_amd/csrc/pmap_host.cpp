@@ -1197,7 +1197,34 @@ struct PieceSource {
 };
 
 // host side of one mapped batch: filter_clusters -> the add_node calls it will make (+ Read::hits, + coverage)
-int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool keep_hits, pmap_coverage_t *cov) {
+// page-locked room for the two hit columns a mapper thread fetches per batch (the copy from the device goes
+// straight into it; into pageable memory it is staged by the runtime at a quarter of the speed), kept by the thread
+struct HitStage {
+    uint32_t *pos = nullptr, *rec = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        release();
+        const size_t want = n + n / 4 + 1024;
+        pos = (uint32_t *) pmap_pinned_alloc(sizeof(uint32_t) * want);
+        rec = (uint32_t *) pmap_pinned_alloc(sizeof(uint32_t) * want);
+        if (!pos || !rec) {
+            release();
+            return false;
+        }
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (pos) pmap_pinned_free(pos);
+        if (rec) pmap_pinned_free(rec);
+        pos = rec = nullptr;
+        cap = 0;
+    }
+};
+
+int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool keep_hits, pmap_coverage_t *cov,
+                 HitStage *stage) {
     pmap_counts_t cn;
     int rc = pmap_result_counts(res, &cn);   // waits for the batch
     if (rc) return rc;
@@ -1212,24 +1239,29 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool
     if ((rc = pmap_filter_clusters(nc, rid.data(), fpos.data(), size.data(), prg.data(), frank.data(), fwd.data(),
                                    lpos.data(), order.data(), alive.data())))
         return rc;
-    std::vector<uint32_t> hpos, hrec;
+    const uint32_t *hpos = nullptr, *hrec = nullptr;
     size_t kept_hits = 0;
     if (keep_hits) {
-        hpos.resize(nh);
-        hrec.resize(nh);
-        if ((rc = pmap_result_hits(res, 1, nullptr, hpos.data(), nullptr, hrec.data(), nullptr))) return rc;
+        if (!stage->reserve(nh)) return pmap_fail(PMAP_EHIP, "out of pinned host memory for a batch's hits");
+        if ((rc = pmap_result_hits(res, 1, nullptr, stage->pos, nullptr, stage->rec, nullptr))) return rc;
+        hpos = stage->pos;
+        hrec = stage->rec;
         for (size_t j = 0; j < nc; ++j)
             if (alive[j]) kept_hits += size[order[j]];
-        out->hits.reserve(kept_hits);
+        out->hits.resize(kept_hits);
     }
+    size_t o = 0;
     for (size_t j = 0; j < nc; ++j) {
         if (!alive[j]) continue;
         const uint64_t c = order[j];
         out->add(prg[c], rid[c], size[c], fwd[c] != 0);       // src/utils.cpp:346-351
-        if (keep_hits)
-            for (uint64_t i = begin[c]; i < begin[c] + size[c]; ++i)
-                out->hits.push_back(PgHit{hpos[i], hrec[i], idx->path_rank[hrec[i]]});
+        if (keep_hits) {
+            // (a cluster never reaches beyond the hits: the rows come from the same batch)
+            const uint64_t e = std::min<uint64_t>(begin[c] + size[c], nh);
+            for (uint64_t i = begin[c]; i < e; ++i) out->hits[o++] = PgHit{hpos[i], hrec[i], idx->path_rank[hrec[i]]};
+        }
     }
+    if (keep_hits) out->hits.resize(o);
     if (cov) {
         // add_hits_to_kmergraphs (src/pangenome/pangraph.cpp:347-383) walks Node::reads, a multiset that
         // holds a read once per add_node call, and for each entry every hit of the read on that node: a
@@ -1257,6 +1289,7 @@ void mapper_thread(Pipeline *pl, void *ctx, std::vector<uint32_t> *cov_fwd, std:
     pmap_reads_t *rd = nullptr;
     pmap_result_t *res = nullptr;
     pmap_coverage_t *cov = nullptr;
+    HitStage stage;
     int rc = pmap_bind_context(ctx);
     if (rc == PMAP_OK && pl->want_cov) rc = pmap_coverage_create(pl->idx, &cov);
     while (rc == PMAP_OK) {
@@ -1287,7 +1320,7 @@ void mapper_thread(Pipeline *pl, void *ctx, std::vector<uint32_t> *cov_fwd, std:
         const double t1 = now_s();
         if (rc == PMAP_OK) rc = pmap_map(pl->idx, rd, &prm, &res);
         const double t2 = now_s();
-        if (rc == PMAP_OK) rc = finish_batch(pl->idx, res, out, pl->keep_hits, cov);
+        if (rc == PMAP_OK) rc = finish_batch(pl->idx, res, out, pl->keep_hits, cov, &stage);
         {
             std::lock_guard<std::mutex> l(pl->m);
             pl->t_upload += t1 - t0;
@@ -1310,6 +1343,7 @@ void mapper_thread(Pipeline *pl, void *ctx, std::vector<uint32_t> *cov_fwd, std:
         rc = pmap_coverage_fetch(cov, cov_fwd->data(), cov_rev->data());
     }
     if (rc != PMAP_OK) pl->fail(rc, pmap_last_error());
+    stage.release();
     pmap_coverage_destroy(cov);
     pmap_result_destroy(res);
     pmap_reads_destroy(rd);

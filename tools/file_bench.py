@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--no-hits", action="store_true")
     ap.add_argument("--batch-mbases", type=int, default=0, help="0 = the library's default")
-    ap.add_argument("--contexts", type=int, default=0, help="mapping contexts on GPU 0 (0 = the library's default, three)")
+    ap.add_argument("--contexts", type=int, default=0, help="mapping contexts on GPU 0 (0 = the library's default, four)")
     args = ap.parse_args()
     import pandora_amd
     from pandora_amd import api, synth
