@@ -11,6 +11,7 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #include <tmmintrin.h>
+#include <immintrin.h>
 #endif
 
 #include <algorithm>
@@ -683,6 +684,34 @@ __attribute__((target("ssse3"))) bool pack_acgt_ssse3(const unsigned char *p, si
     return !bad;
 }
 
+// the same, 32 letters (two words) per step
+__attribute__((target("avx2"))) bool pack_acgt_avx2(const unsigned char *p, size_t n, uint32_t *out) {
+    const __m256i up = _mm256_set1_epi8((char) 0xDF), A = _mm256_set1_epi8('A'), C = _mm256_set1_epi8('C'),
+                  G = _mm256_set1_epi8('G'), T = _mm256_set1_epi8('T'), hi = _mm256_set1_epi8((char) 0xFC),
+                  zero = _mm256_setzero_si256(), ones = _mm256_set1_epi8((char) 0xFF), three = _mm256_set1_epi8(3),
+                  m41 = _mm256_set1_epi16(0x0104), m161 = _mm256_set1_epi32(0x00010010);
+    __m256i acc = zero;
+    size_t i = 0, w = 0;
+    for (; i + 32 <= n; i += 32, w += 2) {
+        const __m256i c = _mm256_loadu_si256((const __m256i *) (p + i)), u = _mm256_and_si256(c, up);
+        const __m256i raw = _mm256_cmpeq_epi8(_mm256_and_si256(c, hi), zero);           // c < 4
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, A), _mm256_cmpeq_epi8(u, C)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(u, G), _mm256_cmpeq_epi8(u, T)));
+        acc = _mm256_or_si256(acc, _mm256_andnot_si256(_mm256_or_si256(ok, raw), ones));
+        __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(c, 1), _mm256_srli_epi16(c, 2)), three);
+        code = _mm256_or_si256(_mm256_andnot_si256(raw, code), _mm256_and_si256(raw, c));
+        // as in the 16-letter form, in each half of the register: its four bytes end up in the half's low word
+        const __m256i nib = _mm256_maddubs_epi16(code, m41);
+        const __m256i byt = _mm256_madd_epi16(nib, m161);
+        const __m256i b16 = _mm256_packs_epi32(byt, byt), b8 = _mm256_packus_epi16(b16, b16);
+        out[w] = __builtin_bswap32((uint32_t) _mm256_extract_epi32(b8, 0));
+        out[w + 1] = __builtin_bswap32((uint32_t) _mm256_extract_epi32(b8, 4));
+    }
+    const bool bad = _mm256_movemask_epi8(acc) != 0;
+    // what is left, fewer than 32 letters, by the 16-letter form (whole words: i is a multiple of 16)
+    return pack_acgt_ssse3(p + i, n - i, out + w) && !bad;
+}
+
 bool pack_acgt_plain(const unsigned char *p, size_t n, uint32_t *out) {
     bool bad = false;
     for (size_t i = 0, w = 0; i < n; i += 16, ++w) {
@@ -699,8 +728,8 @@ bool pack_acgt_plain(const unsigned char *p, size_t n, uint32_t *out) {
 }
 
 bool pack_acgt(const unsigned char *p, size_t n, uint32_t *out) {
-    static const bool ssse3 = __builtin_cpu_supports("ssse3");
-    return ssse3 ? pack_acgt_ssse3(p, n, out) : pack_acgt_plain(p, n, out);
+    static const bool avx2 = __builtin_cpu_supports("avx2"), ssse3 = __builtin_cpu_supports("ssse3");
+    return avx2 ? pack_acgt_avx2(p, n, out) : ssse3 ? pack_acgt_ssse3(p, n, out) : pack_acgt_plain(p, n, out);
 }
 
 // FastaqHandler's `read` member kept inside a batch's buffer: the lines of a read are copied once, to where
@@ -1449,9 +1478,11 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     pl.a = a;
     pl.keep_hits = !(a->flags & PMAP_PG_NO_HITS);
     pl.want_cov = (a->flags & PMAP_PG_COVERAGE) != 0;
-    // 32 Mbases per batch: the pinned buffers stay cache- and TLB-friendly on the host (a 2 GB FASTQ mapped at
-    // 2.9 Gbases/s with 32-Mbase batches and at 1.6 with 256-Mbase ones) and the GPU is far from busy either way.
-    // A piece of a mapped file becomes one batch: with qualities and headers about two bytes per base.
+    // A piece of a mapped file becomes one batch (with qualities and headers about two bytes per base).  Big pieces
+    // cost the mapper threads less per base (8 GB of FASTQ on 16 cores: 64 MB pieces 42-49 Gbases/s, 96-128 MB 52-56,
+    // 192-256 MB 45-51), small files want enough pieces for every parser thread: a quarter of a thread's share of
+    // the file, between 16 and 128 MB (set below, once the file is open).  The sequential reader cuts its batches
+    // at 32 Mbases.
     pl.batch_bases = a->batch_bases ? a->batch_bases : (32ull << 20);
     pl.piece_bytes = a->batch_bases ? a->batch_bases : (64ull << 20);
 
@@ -1473,6 +1504,8 @@ extern "C" int pmap_pangraph_from_read_file(const char *reads_path, const pmap_i
     pl.pieces = parallel;
     if (parallel) {
         src.cur = mapped.base;
+        if (!a->batch_bases)
+            pl.piece_bytes = std::min<uint64_t>(128ull << 20, std::max<uint64_t>(16ull << 20, mapped.size / (4ull * std::max(1u, n_parse))));
         const unsigned workers = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(n_parse, mapped.size / std::max<uint64_t>(pl.piece_bytes, 1) + 1));
         pl.max_buffers = workers + 2 * contexts.size() + 2;
         for (unsigned i = 0; i < workers; ++i) threads.emplace_back(&PieceSource::worker, &src);
