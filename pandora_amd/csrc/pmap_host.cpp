@@ -1098,6 +1098,7 @@ struct PieceSource {
 
     void worker() {
         const char *file_end = file->base + file->size;
+        bool populate = !(getenv("PMAP_POPULATE") && atoi(getenv("PMAP_POPULATE")) == 0);
         for (;;) {
             // the buffer first, then the piece: whoever holds the lowest unparsed piece always has a buffer
             const double tw = now_s();
@@ -1116,6 +1117,12 @@ struct PieceSource {
                 end = begin + pl->piece_bytes >= file_end ? file_end : find_seam(begin + pl->piece_bytes, file_end);
                 cur = end;
                 b->seq = next_piece++;
+            }
+            // the piece's pages into this process' page table in one go (one call instead of a fault per 64 KB;
+            // kernels without it answer EINVAL and the pages come in by faults as before).  PMAP_POPULATE=0: never
+            if (populate) {
+                const uintptr_t page = 4096, lo = (uintptr_t) begin & ~(page - 1);
+                if (madvise((void *) lo, (size_t) ((uintptr_t) end - lo), MADV_POPULATE_READ) != 0) populate = false;
             }
             // a read is never longer than its piece
             if (!b->reserve((size_t) (end - begin) + 64)) {
