@@ -1610,6 +1610,16 @@ extern "C" int pmap_result_hits(const pmap_result_t *res, int sorted, uint32_t *
     return PMAP_OK;
 }
 
+// (library-internal) the path ranks of the sorted hits, for the read-file pipeline: one more column from the device
+// costs less than a lookup in the index's rank table per hit on the host
+int pmap_result_hit_ranks(const pmap_result *res, uint32_t *rank) {
+    if (!res || !rank) return pmap_fail(PMAP_EINVAL, "null argument");
+    if (int rc0 = settled(res)) return rc0;
+    const size_t n = res->counts.n_hits;
+    if (n) HIP_TRY(hipMemcpy(rank, res->s_rank.p, n * 4, hipMemcpyDeviceToHost));
+    return PMAP_OK;
+}
+
 extern "C" int pmap_result_clusters(const pmap_result_t *res, uint64_t *begin, uint32_t *size, uint32_t *read_id,
                                     uint32_t *prg_id, uint8_t *is_forward, uint32_t *first_pos, uint32_t *last_pos,
                                     uint32_t *first_rank) {

@@ -313,6 +313,25 @@ struct PgHit {
     uint32_t pos, rec, rank;
 };
 
+// The hits of a batch are written once, every element, right after the array is made: the array is not
+// zeroed first (a second pass over memory that is about to be overwritten), and its pages are mapped in one call
+// (madvise MADV_POPULATE_WRITE; without it they come in by a fault per page while the records are written).
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U> void construct(U *p) { ::new ((void *) p) U; }
+    template <typename U, typename... Args> void construct(U *p, Args &&...args) { ::new ((void *) p) U(std::forward<Args>(args)...); }
+};
+typedef std::vector<PgHit, NoInitAlloc<PgHit>> PgHitVec;
+
+static void populate_for_write(void *p, size_t bytes) {
+    static bool works = true;
+    const uintptr_t page = 4096, lo = ((uintptr_t) p + page - 1) & ~(page - 1), hi = ((uintptr_t) p + bytes) & ~(page - 1);
+    if (works && hi > lo && bytes >= (1u << 20) && madvise((void *) lo, hi - lo, MADV_POPULATE_WRITE) != 0) works = false;
+}
+
 // A run of add_node calls and what they leave in pangenome::Graph::reads.  The read loop numbers the reads in
 // file order and a read's calls come together (clusterComp orders by read first), so the reads are kept in rising
 // id order: read i has the nodes rn_prg / rn_orient [read_start[i], read_start[i + 1]), the last one up to the end.
@@ -370,9 +389,9 @@ struct pmap_pangraph : PgCalls {
     // Read::hits in add_node call order, each call's cluster in pComp order: one segment per mapped batch, kept as
     // the mapper thread made it (copying 10^7 records once more on the retiring thread made that thread the slow
     // one); `flat` = the segments in one array, made when hits are asked for by global index
-    std::vector<std::vector<PgHit>> hit_seg;
+    std::vector<PgHitVec> hit_seg;
     size_t n_hits = 0;
-    std::vector<PgHit> flat;
+    PgHitVec flat;
     bool flat_valid = false;
     bool keep_hits = true;
     std::vector<uint64_t> by_path;    // hits in Read::hits order (indices into `hits`), built on demand
@@ -842,7 +861,7 @@ struct ReadLoop {
 };
 
 struct Outcome : PgCalls {  // what one mapped batch contributes to the pangraph
-    std::vector<PgHit> hits;        // call order, each call's cluster in pComp order
+    PgHitVec hits;                  // call order, each call's cluster in pComp order
 };
 
 struct Pipeline {
@@ -1236,7 +1255,7 @@ struct PieceSource {
 // page-locked room for the two hit columns a mapper thread fetches per batch (the copy from the device goes
 // straight into it; into pageable memory it is staged by the runtime at a quarter of the speed), kept by the thread
 struct HitStage {
-    uint32_t *pos = nullptr, *rec = nullptr;
+    uint32_t *pos = nullptr, *rec = nullptr, *rank = nullptr;
     size_t cap = 0;
     bool reserve(size_t n) {
         if (n <= cap) return true;
@@ -1244,7 +1263,8 @@ struct HitStage {
         const size_t want = n + n / 4 + 1024;
         pos = (uint32_t *) pmap_pinned_alloc(sizeof(uint32_t) * want);
         rec = (uint32_t *) pmap_pinned_alloc(sizeof(uint32_t) * want);
-        if (!pos || !rec) {
+        rank = (uint32_t *) pmap_pinned_alloc(sizeof(uint32_t) * want);
+        if (!pos || !rec || !rank) {
             release();
             return false;
         }
@@ -1254,7 +1274,8 @@ struct HitStage {
     void release() {
         if (pos) pmap_pinned_free(pos);
         if (rec) pmap_pinned_free(rec);
-        pos = rec = nullptr;
+        if (rank) pmap_pinned_free(rank);
+        pos = rec = rank = nullptr;
         cap = 0;
     }
 };
@@ -1275,16 +1296,20 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool
     if ((rc = pmap_filter_clusters(nc, rid.data(), fpos.data(), size.data(), prg.data(), frank.data(), fwd.data(),
                                    lpos.data(), order.data(), alive.data())))
         return rc;
-    const uint32_t *hpos = nullptr, *hrec = nullptr;
+    const uint32_t *hpos = nullptr, *hrec = nullptr, *hrank = nullptr;
     size_t kept_hits = 0;
     if (keep_hits) {
         if (!stage->reserve(nh)) return pmap_fail(PMAP_EHIP, "out of pinned host memory for a batch's hits");
-        if ((rc = pmap_result_hits(res, 1, nullptr, stage->pos, nullptr, stage->rec, nullptr))) return rc;
+        if ((rc = pmap_result_hits(res, 1, nullptr, stage->pos, nullptr, stage->rec, nullptr)) ||
+            (rc = pmap_result_hit_ranks(res, stage->rank)))
+            return rc;
         hpos = stage->pos;
         hrec = stage->rec;
+        hrank = stage->rank;
         for (size_t j = 0; j < nc; ++j)
             if (alive[j]) kept_hits += size[order[j]];
         out->hits.resize(kept_hits);
+        populate_for_write(out->hits.data(), sizeof(PgHit) * kept_hits);
     }
     size_t o = 0;
     for (size_t j = 0; j < nc; ++j) {
@@ -1294,7 +1319,7 @@ int finish_batch(const pmap_index_t *idx, pmap_result_t *res, Outcome *out, bool
         if (keep_hits) {
             // (a cluster never reaches beyond the hits: the rows come from the same batch)
             const uint64_t e = std::min<uint64_t>(begin[c] + size[c], nh);
-            for (uint64_t i = begin[c]; i < e; ++i) out->hits[o++] = PgHit{hpos[i], hrec[i], idx->path_rank[hrec[i]]};
+            for (uint64_t i = begin[c]; i < e; ++i) out->hits[o++] = PgHit{hpos[i], hrec[i], hrank[i]};
         }
     }
     if (keep_hits) out->hits.resize(o);

@@ -105,6 +105,7 @@ struct pmap_index {
 };
 
 // pinned host memory (hipHostMalloc), nullptr on failure
+int pmap_result_hit_ranks(const pmap_result *res, uint32_t *rank);
 void *pmap_pinned_alloc(size_t bytes);
 void pmap_pinned_free(void *p);
 
