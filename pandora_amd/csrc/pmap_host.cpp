@@ -5,6 +5,7 @@
 // pangraph_from_read_file (src/utils.cpp:379-455).
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <atomic>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -327,9 +328,11 @@ struct NoInitAlloc : std::allocator<T> {
 typedef std::vector<PgHit, NoInitAlloc<PgHit>> PgHitVec;
 
 static void populate_for_write(void *p, size_t bytes) {
-    static bool works = true;
+    static std::atomic<bool> works{true};       // (kernels without it answer EINVAL once)
     const uintptr_t page = 4096, lo = ((uintptr_t) p + page - 1) & ~(page - 1), hi = ((uintptr_t) p + bytes) & ~(page - 1);
-    if (works && hi > lo && bytes >= (1u << 20) && madvise((void *) lo, hi - lo, MADV_POPULATE_WRITE) != 0) works = false;
+    if (works.load(std::memory_order_relaxed) && hi > lo && bytes >= (1u << 20) &&
+        madvise((void *) lo, hi - lo, MADV_POPULATE_WRITE) != 0)
+        works.store(false, std::memory_order_relaxed);
 }
 
 // A run of add_node calls and what they leave in pangenome::Graph::reads.  The read loop numbers the reads in
